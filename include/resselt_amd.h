@@ -1,0 +1,154 @@
+/*
+ * resselt_amd.h — C-ABI of the MI355X (gfx950) super-resolution forward-pass engine.
+ *
+ * The reference (rewaifu/resselt) has NO FFI: its hot path is `model.forward(x)` of
+ * nn.Modules that delegate every operation to PyTorch ATen.  Each entry point below
+ * names the reference ATen op sequence (file:line under /root/reference) that it
+ * replaces.  The library is loaded with ctypes by `resselt_amd/engine/lib.py`; the
+ * binding a maintainer of the reference would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  All data pointers are DEVICE pointers
+ *     owned by the caller (PyTorch caching allocator); the library never allocates,
+ *     never synchronises and keeps no global state besides a thread-local error string.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *   - return value: 0 = ok, < 0 = argument error (RSA_E_*), > 0 = hipError_t from a launch.
+ *
+ * Activation storage ("split planes", the engine's internal HBM layout)
+ *   A C-channel feature map of H x W pixels is stored channel-blocked by 8 ("NCHW8c"):
+ *       hi[n][plane = c/8][y][x][c%8]   bf16   (round-to-nearest-even of the f32 value)
+ *       lo[n][plane = c/8][y][x][c%8]   bf16   (bf16 of the rounding residual v - hi)
+ *   One (plane,y,x) cell is a 16-byte "unit": 8 channels of one pixel = one MFMA
+ *   k-group operand (v_mfma_f32_16x16x32_bf16 B fragment) and one coalesced 16 B lane load.
+ *   Dense concatenation (reference torch.cat along dim 1) is a plane offset into a shared
+ *   buffer, never a copy.  Residual streams are additionally kept in f32 as
+ *       f32[n][plane4 = c/4][y][x][c%4]          ("NCHW4c")
+ *   which is exactly the accumulator fragment of the MFMA (4 consecutive channels / lane).
+ */
+#ifndef RESSELT_AMD_H
+#define RESSELT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSA_VERSION 100 /* 0.1.0 */
+
+/* error codes (negative = argument errors) */
+#define RSA_OK 0
+#define RSA_E_ARG (-1)       /* null / out-of-range argument */
+#define RSA_E_UNSUPPORTED (-2) /* combination not compiled in */
+#define RSA_E_ALIGN (-3)     /* pointer not 16-byte aligned */
+
+/* activation selector of the fused epilogue */
+enum rsa_act {
+  RSA_ACT_NONE = 0,
+  RSA_ACT_LRELU = 1, /* act_param = negative slope; reference utilities/block.py:17-30 */
+  RSA_ACT_MISH = 2,  /* reference archs/spanplus/arch.py:121 (nn.Mish)                  */
+  RSA_ACT_SILU = 3,  /* reference archs/span/arch.py:164 (nn.SiLU)                      */
+  RSA_ACT_GELU = 4,  /* erf GELU, reference archs/swinir/arch.py:34-40 (nn.GELU)        */
+  RSA_ACT_SPAB_GATE = 5 /* y = (acc + res1) * (sigmoid(acc) - 0.5); spanplus/arch.py:126-127 */
+};
+
+/* dtype of plain NCHW tensors crossing the boundary */
+enum rsa_dtype { RSA_F32 = 0, RSA_F16 = 1, RSA_BF16 = 2 };
+
+/*
+ * One fused convolution launch.
+ *
+ * Replaces, in one kernel, the reference sequence
+ *   [torch.cat of earlier outputs] -> [nn.Upsample(x2, nearest)] -> nn.Conv2d(k=1|3, s=1, zero pad k/2, bias)
+ *   -> [activation] -> [* alpha + residual] -> [* beta + residual2] -> [nn.PixelShuffle]
+ * i.e. utilities/block.py:148-200 (conv_block), :454-465 (ResidualDenseBlock_5C.forward),
+ * :340-344 (RRDB.forward), :83-91 (ShortcutBlock), :510-537 (upconv_block), :477-507
+ * (pixelshuffle_block); archs/spanplus/arch.py:94-130; archs/swinir/arch.py:34-40 (Linear = k1 conv).
+ *
+ * Arithmetic: implicit GEMM on v_mfma_f32_16x16x32_bf16, f32 accumulate.
+ *   products == 1 : acc += hi(a)*hi(w)                                 ("bf16")
+ *   products == 3 : acc += hi(a)*hi(w) + lo(a)*hi(w) + hi(a)*lo(w)     ("bf16x3", ~16-bit operands)
+ */
+typedef struct rsa_conv_params {
+  /* geometry */
+  int32_t batch;        /* N */
+  int32_t H, W;         /* OUTPUT height/width in pixels (before pixel_shuffle) */
+  int32_t ksize;        /* 1 or 3 */
+  int32_t upsample2x;   /* 1: input map is (H/2 x W/2), nearest-upsampled on read */
+  int32_t cin_planes;   /* input planes (of 8 channels) consumed, starting at in_hi/in_lo */
+  int32_t cout;         /* real output channels */
+  int32_t products;     /* 1 or 3 */
+
+  /* input, split planes; strides in 16-byte units */
+  const void* in_hi;
+  const void* in_lo;        /* may be NULL when products == 1 */
+  int64_t in_plane_stride;  /* units between planes  (= Hin*Win for a dense tensor) */
+  int64_t in_batch_stride;  /* units between images  */
+
+  /* weights packed by rsa_pack_conv_weights_host layout, bias f32[cout_pad] */
+  const void* w_packed;
+  const float* bias; /* may be NULL */
+
+  /* epilogue */
+  int32_t act;      /* enum rsa_act */
+  float act_param;  /* LeakyReLU slope */
+  float alpha;      /* used when res1 != NULL (or act == SPAB gate) */
+  const float* res1; /* f32 NCHW4c [N][ceil(cout/4)][H][W][4] */
+  float beta;
+  const float* res2;
+
+  /* outputs; each may be NULL */
+  void* out_hi;             /* split planes, written at plane offset out_plane_off */
+  void* out_lo;             /* NULL allowed (bf16 single-plane consumers) */
+  int32_t out_plane_off;    /* first plane written (cout/8 planes follow; tail channels zeroed) */
+  int64_t out_plane_stride; /* units */
+  int64_t out_batch_stride; /* units */
+  float* out_f32;           /* f32 NCHW4c residual stream */
+  void* pre_hi;             /* optional: PRE-activation value as split planes (SPAB `out1`, */
+  void* pre_lo;             /*   archs/spanplus/arch.py:118,128-129), same strides/off as out_* */
+  int32_t pre_plane_off;
+  int64_t pre_plane_stride;
+  int64_t pre_batch_stride;
+
+  void* out_nchw;           /* final plain tensor [N][cout/r^2][H*r][W*r], dtype out_dtype */
+  int32_t out_dtype;        /* enum rsa_dtype */
+  int32_t pixel_shuffle;    /* r >= 1 (depth-to-space factor applied while storing out_nchw) */
+  float out_scale;          /* out_nchw value = v * out_scale + out_shift[oc]  (SwinIR x/img_range + mean, */
+  const float* out_shift;   /*   archs/swinir/arch.py:1013); NULL = none */
+} rsa_conv_params;
+
+/* Launch `n` fused convolutions in order on `stream` (one host call per forward pass). */
+int rsa_conv2d(const rsa_conv_params* p, void* stream);
+int rsa_conv2d_list(const rsa_conv_params* list, int32_t n, void* stream);
+
+/* Bytes of the packed weight blob for a (cout, cin_planes, ksize, products) convolution. */
+int64_t rsa_packed_weight_bytes(int32_t cout, int32_t cin_planes, int32_t ksize, int32_t products);
+
+/*
+ * Weight packing happens on the host side of the boundary (resselt_amd/engine/pack.py,
+ * torch tensor ops, at load_state_dict time — reference registry.py:113); the blob layout is
+ *   [cout_slab][chunk q][tap t][cout_tile][hi|lo][lane 0..63][8] bf16
+ * with, for lane l: cout = 16*tile + (l & 15), cin = 32*q + 8*(l >> 4) + j   (DESIGN.md §3).
+ */
+
+/*
+ * Plain NCHW tensor -> split planes, with per-channel affine  v = (x - mean[c]) * scale.
+ * Replaces the implicit NCHW read of the first conv and `(x - mean) * img_range`
+ * (archs/span/arch.py:232-234, archs/swinir/arch.py:966-967).  Channels padded to 8 with zeros.
+ */
+int rsa_nchw_to_planes(const void* x, int32_t dtype, int32_t batch, int32_t C, int32_t H, int32_t W, const float* mean,
+                       float scale, void* out_hi, void* out_lo, int64_t out_plane_stride, int64_t out_batch_stride,
+                       void* stream);
+
+/* split planes / f32 NCHW4c -> plain NCHW (debug + parity of intermediates) */
+int rsa_planes_to_nchw(const void* hi, const void* lo, int64_t plane_stride, int64_t batch_stride, int32_t batch,
+                       int32_t C, int32_t H, int32_t W, float* out, void* stream);
+
+/* version / errors */
+int rsa_version(void);
+const char* rsa_last_error_string(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RESSELT_AMD_H */

@@ -1,0 +1,150 @@
+// capi.hip — extern "C" surface of libresselt_amd.so (see include/resselt_amd.h) and the
+// layout-conversion kernels either side of the convolution path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+#include "resselt_amd.h"
+
+namespace rsa {
+
+static thread_local char g_err[256] = "";
+
+int set_error(int code, const char* msg) {
+  if (code > 0)
+    snprintf(g_err, sizeof(g_err), "%s (hipError %d: %s)", msg, code, hipGetErrorString((hipError_t)code));
+  else
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+template <typename T>
+__device__ __forceinline__ float ld_as_float(const void* p, int64_t i) {
+  return (float)((const T*)p)[i];
+}
+
+// one thread per (n, plane, y, x) unit: gathers 8 channels of one pixel from the plain NCHW tensor
+__global__ void nchw_to_planes_kernel(const void* x, int dtype, int batch, int C, int H, int W, const float* mean, float scale,
+                                      void* out_hi, void* out_lo, int64_t plane_stride, int64_t batch_stride) {
+  const int planes = (C + 7) >> 3;
+  const int64_t HW = (int64_t)H * W;
+  const int64_t total = (int64_t)batch * planes * HW;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = idx % HW;
+    const int64_t t = idx / HW;
+    const int pl = (int)(t % planes);
+    const int n = (int)(t / planes);
+    bf16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = pl * 8 + j;
+      float v = 0.f;
+      if (c < C) {
+        const int64_t src = ((int64_t)n * C + c) * HW + pix;
+        if (dtype == RSA_F32)
+          v = ld_as_float<float>(x, src);
+        else if (dtype == RSA_F16)
+          v = ld_as_float<_Float16>(x, src);
+        else
+          v = ld_as_float<__bf16>(x, src);
+        if (mean != nullptr) v -= mean[c];
+        v *= scale;
+      }
+      const __bf16 hb = (__bf16)v;
+      h[j] = hb;
+      l[j] = (__bf16)(v - (float)hb);
+    }
+    const int64_t unit = (int64_t)n * batch_stride + (int64_t)pl * plane_stride + pix;
+    ((bf16x8*)out_hi)[unit] = h;
+    if (out_lo != nullptr) ((bf16x8*)out_lo)[unit] = l;
+  }
+}
+
+__global__ void planes_to_nchw_kernel(const void* hi, const void* lo, int64_t plane_stride, int64_t batch_stride, int batch, int C, int H,
+                                      int W, float* out) {
+  const int64_t HW = (int64_t)H * W;
+  const int64_t total = (int64_t)batch * C * HW;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = idx % HW;
+    const int64_t t = idx / HW;
+    const int c = (int)(t % C);
+    const int n = (int)(t / C);
+    const int64_t e = ((int64_t)n * batch_stride + (int64_t)(c >> 3) * plane_stride + pix) * 8 + (c & 7);
+    float v = (float)((const __bf16*)hi)[e];
+    if (lo != nullptr) v += (float)((const __bf16*)lo)[e];
+    out[idx] = v;
+  }
+}
+
+static unsigned grid_for(int64_t total, int block) {
+  int64_t g = (total + block - 1) / block;
+  if (g > 256 * 32) g = 256 * 32;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace rsa
+
+extern "C" {
+
+int rsa_version(void) { return RSA_VERSION; }
+
+const char* rsa_last_error_string(void) { return rsa::g_err; }
+
+int rsa_conv2d(const rsa_conv_params* p, void* stream) {
+  if (p == nullptr) return rsa::set_error(RSA_E_ARG, "rsa_conv2d: null params");
+  return rsa::conv_launch(*p, (hipStream_t)stream);
+}
+
+int rsa_conv2d_list(const rsa_conv_params* list, int32_t n, void* stream) {
+  if (list == nullptr || n < 0) return rsa::set_error(RSA_E_ARG, "rsa_conv2d_list: null list");
+  for (int32_t i = 0; i < n; ++i) {
+    const int rc = rsa::conv_launch(list[i], (hipStream_t)stream);
+    if (rc != RSA_OK) {
+      char buf[200];
+      snprintf(buf, sizeof(buf), "rsa_conv2d_list: entry %d: %.150s", i, rsa::g_err);
+      // keep the hip error text that conv_launch recorded
+      strncpy(rsa::g_err, buf, sizeof(rsa::g_err) - 1);
+      return rc;
+    }
+  }
+  return RSA_OK;
+}
+
+int rsa_conv_cout_tiles(int32_t cout) { return rsa::conv_nct(cout); }
+
+int64_t rsa_packed_weight_bytes(int32_t cout, int32_t cin_planes, int32_t ksize, int32_t products) {
+  if (cout < 1 || cin_planes < 1 || (ksize != 1 && ksize != 3) || (products != 1 && products != 3)) return RSA_E_ARG;
+  const int64_t ct = (cout + 15) / 16;
+  const int64_t chunks = (cin_planes + 3) / 4;
+  const int64_t nhl = products == 3 ? 2 : 1;
+  return chunks * ksize * ksize * ct * nhl * 64 * 16;
+}
+
+int rsa_nchw_to_planes(const void* x, int32_t dtype, int32_t batch, int32_t C, int32_t H, int32_t W, const float* mean, float scale,
+                       void* out_hi, void* out_lo, int64_t out_plane_stride, int64_t out_batch_stride, void* stream) {
+  if (x == nullptr || out_hi == nullptr || batch < 1 || C < 1 || H < 1 || W < 1) return rsa::set_error(RSA_E_ARG, "nchw_to_planes: bad argument");
+  if (dtype < RSA_F32 || dtype > RSA_BF16) return rsa::set_error(RSA_E_ARG, "nchw_to_planes: bad dtype");
+  if (((uintptr_t)out_hi | (uintptr_t)out_lo) & 15) return rsa::set_error(RSA_E_ALIGN, "nchw_to_planes: outputs must be 16-byte aligned");
+  const int64_t total = (int64_t)batch * ((C + 7) / 8) * H * W;
+  hipLaunchKernelGGL(rsa::nchw_to_planes_kernel, dim3(rsa::grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, dtype, batch, C, H, W,
+                     mean, scale, out_hi, out_lo, out_plane_stride, out_batch_stride);
+  const int rc = (int)hipGetLastError();
+  return rc ? rsa::set_error(rc, "nchw_to_planes: launch failed") : RSA_OK;
+}
+
+int rsa_planes_to_nchw(const void* hi, const void* lo, int64_t plane_stride, int64_t batch_stride, int32_t batch, int32_t C, int32_t H, int32_t W,
+                       float* out, void* stream) {
+  if (hi == nullptr || out == nullptr || batch < 1 || C < 1 || H < 1 || W < 1) return rsa::set_error(RSA_E_ARG, "planes_to_nchw: bad argument");
+  const int64_t total = (int64_t)batch * C * H * W;
+  hipLaunchKernelGGL(rsa::planes_to_nchw_kernel, dim3(rsa::grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, hi, lo, plane_stride,
+                     batch_stride, batch, C, H, W, out);
+  const int rc = (int)hipGetLastError();
+  return rc ? rsa::set_error(rc, "planes_to_nchw: launch failed") : RSA_OK;
+}
+
+}  // extern "C"

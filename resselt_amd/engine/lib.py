@@ -1,0 +1,138 @@
+"""ctypes binding of ``libresselt_amd.so`` (C-ABI declared in ``include/resselt_amd.h``).
+
+The library is the product: there is no CPU or PyTorch fallback behind these wrappers.
+``load()`` raises ``RuntimeError`` when the shared object is missing or a symbol is absent,
+and every call raises ``RuntimeError`` with ``rsa_last_error_string()`` on a non-zero status.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_LIB_NAME = 'libresselt_amd.so'
+_lib: Optional[C.CDLL] = None
+
+# enum rsa_act
+ACT_NONE, ACT_LRELU, ACT_MISH, ACT_SILU, ACT_GELU, ACT_SPAB_GATE = range(6)
+# enum rsa_dtype
+F32, F16, BF16 = range(3)
+
+
+class ConvParams(C.Structure):
+    """Mirror of ``struct rsa_conv_params`` (include/resselt_amd.h); field order is the ABI."""
+
+    _fields_ = [
+        ('batch', C.c_int32),
+        ('H', C.c_int32),
+        ('W', C.c_int32),
+        ('ksize', C.c_int32),
+        ('upsample2x', C.c_int32),
+        ('cin_planes', C.c_int32),
+        ('cout', C.c_int32),
+        ('products', C.c_int32),
+        ('in_hi', C.c_void_p),
+        ('in_lo', C.c_void_p),
+        ('in_plane_stride', C.c_int64),
+        ('in_batch_stride', C.c_int64),
+        ('w_packed', C.c_void_p),
+        ('bias', C.c_void_p),
+        ('act', C.c_int32),
+        ('act_param', C.c_float),
+        ('alpha', C.c_float),
+        ('res1', C.c_void_p),
+        ('beta', C.c_float),
+        ('res2', C.c_void_p),
+        ('out_hi', C.c_void_p),
+        ('out_lo', C.c_void_p),
+        ('out_plane_off', C.c_int32),
+        ('out_plane_stride', C.c_int64),
+        ('out_batch_stride', C.c_int64),
+        ('out_f32', C.c_void_p),
+        ('pre_hi', C.c_void_p),
+        ('pre_lo', C.c_void_p),
+        ('pre_plane_off', C.c_int32),
+        ('pre_plane_stride', C.c_int64),
+        ('pre_batch_stride', C.c_int64),
+        ('out_nchw', C.c_void_p),
+        ('out_dtype', C.c_int32),
+        ('pixel_shuffle', C.c_int32),
+        ('out_scale', C.c_float),
+        ('out_shift', C.c_void_p),
+    ]
+
+
+# every symbol include/resselt_amd.h declares (checked by tests/test_capi_symbols.py)
+EXPORTS = (
+    'rsa_version',
+    'rsa_last_error_string',
+    'rsa_conv2d',
+    'rsa_conv2d_list',
+    'rsa_conv_cout_tiles',
+    'rsa_packed_weight_bytes',
+    'rsa_nchw_to_planes',
+    'rsa_planes_to_nchw',
+)
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), _LIB_NAME)
+
+
+def load() -> C.CDLL:
+    """Load the HIP library once; fail loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f'{_LIB_NAME} not found at {path}: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950). resselt_amd has no CPU fallback.'
+        )
+    lib = C.CDLL(path)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise RuntimeError(f'{path} does not export {name}; rebuild the library')
+    lib.rsa_version.restype = C.c_int
+    lib.rsa_last_error_string.restype = C.c_char_p
+    lib.rsa_conv2d.argtypes = [C.POINTER(ConvParams), C.c_void_p]
+    lib.rsa_conv2d.restype = C.c_int
+    lib.rsa_conv2d_list.argtypes = [C.POINTER(ConvParams), C.c_int32, C.c_void_p]
+    lib.rsa_conv2d_list.restype = C.c_int
+    lib.rsa_conv_cout_tiles.argtypes = [C.c_int32]
+    lib.rsa_conv_cout_tiles.restype = C.c_int
+    lib.rsa_packed_weight_bytes.argtypes = [C.c_int32] * 4
+    lib.rsa_packed_weight_bytes.restype = C.c_int64
+    lib.rsa_nchw_to_planes.argtypes = [
+        C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_float,
+        C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+    ]  # fmt: skip
+    lib.rsa_nchw_to_planes.restype = C.c_int
+    lib.rsa_planes_to_nchw.argtypes = [
+        C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+    ]  # fmt: skip
+    lib.rsa_planes_to_nchw.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().rsa_last_error_string()
+        raise RuntimeError(f'{what} failed (status {rc}): {msg.decode() if msg else "?"}')
+
+
+def conv2d_list(params: 'C.Array[ConvParams] | list[ConvParams]', stream: int) -> None:
+    """Launch a list of fused convolutions in order on ``stream`` with one host call."""
+    lib = load()
+    if isinstance(params, list):
+        arr = (ConvParams * len(params))(*params)
+    else:
+        arr = params
+    check(lib.rsa_conv2d_list(arr, len(arr), C.c_void_p(stream)), 'rsa_conv2d_list')
+
+
+def cout_tiles(cout: int) -> int:
+    return int(load().rsa_conv_cout_tiles(cout))

@@ -1,0 +1,184 @@
+"""Python-side builders for the C-ABI launch descriptors (no arithmetic happens here)."""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import lib as L
+from .pack import pack_conv_weights, pad_bias
+from .tensors import Planes
+
+_TORCH_TO_RSA = {torch.float32: L.F32, torch.float16: L.F16, torch.bfloat16: L.BF16}
+
+
+def rsa_dtype(dt: torch.dtype) -> int:
+    try:
+        return _TORCH_TO_RSA[dt]
+    except KeyError:
+        raise TypeError(f'resselt_amd supports float32/float16/bfloat16 tensors, got {dt}') from None
+
+
+def current_stream_ptr(device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(x: torch.Tensor, what: str) -> None:
+    """The engine has no CPU path: fail loudly instead of silently computing elsewhere."""
+    if not x.is_cuda:
+        raise RuntimeError(
+            f'{what}: resselt_amd runs on MI355X HIP kernels only; got a tensor on {x.device}. '
+            'Move the model and input to a cuda (ROCm) device.'
+        )
+
+
+@dataclass
+class ConvWeights:
+    """One convolution's device-resident, pre-packed parameters."""
+
+    packed: torch.Tensor  # bf16 blob, see pack.py
+    bias: torch.Tensor  # f32, padded to 16
+    cout: int
+    cin: int
+    cin_planes: int
+    ksize: int
+    products: int
+
+    @staticmethod
+    def from_oihw(w: torch.Tensor, b: torch.Tensor | None, products: int, cin_planes: int | None = None, device=None) -> 'ConvWeights':
+        device = device if device is not None else w.device
+        cout, cin, k, _ = w.shape
+        if cin_planes is None:
+            cin_planes = (cin + 7) // 8
+        packed = pack_conv_weights(w.to(device=device, dtype=torch.float32), cin_planes, products)
+        bias = pad_bias(None if b is None else b.to(device), cout, device)
+        return ConvWeights(packed, bias, cout, cin, cin_planes, k, products)
+
+
+def conv_params(
+    wts: ConvWeights,
+    x: Planes,
+    H: int,
+    W: int,
+    *,
+    in_plane0: int = 0,
+    cin_planes: int | None = None,
+    upsample2x: bool = False,
+    act: int = L.ACT_NONE,
+    act_param: float = 0.0,
+    res1: torch.Tensor | None = None,
+    alpha: float = 1.0,
+    res2: torch.Tensor | None = None,
+    beta: float = 1.0,
+    out: Planes | None = None,
+    out_plane_off: int = 0,
+    out_f32: torch.Tensor | None = None,
+    pre: Planes | None = None,
+    pre_plane_off: int = 0,
+    out_nchw: torch.Tensor | None = None,
+    pixel_shuffle: int = 1,
+    out_scale: float = 1.0,
+    out_shift: torch.Tensor | None = None,
+) -> L.ConvParams:
+    """Fill one ``rsa_conv_params``. ``H``, ``W`` are the OUTPUT size of the convolution."""
+    p = L.ConvParams()
+    p.batch = x.n
+    p.H, p.W = H, W
+    p.ksize = wts.ksize
+    p.upsample2x = 1 if upsample2x else 0
+    p.cin_planes = wts.cin_planes if cin_planes is None else cin_planes
+    if p.cin_planes != wts.cin_planes:
+        raise ValueError('cin_planes does not match the packed weights')
+    p.cout = wts.cout
+    p.products = wts.products
+    exp_h, exp_w = (H // 2, W // 2) if upsample2x else (H, W)
+    if (x.h, x.w) != (exp_h, exp_w):
+        raise ValueError(f'input planes are {x.h}x{x.w}, expected {exp_h}x{exp_w}')
+    if in_plane0 + p.cin_planes > x.planes:
+        raise ValueError('input plane range exceeds the buffer')
+    p.in_hi = x.hi_ptr(in_plane0)
+    p.in_lo = x.lo_ptr(in_plane0)
+    if wts.products == 3 and x.lo is None:
+        raise ValueError('products=3 needs lo planes')
+    p.in_plane_stride = x.plane_stride
+    p.in_batch_stride = x.batch_stride
+    p.w_packed = wts.packed.data_ptr()
+    p.bias = wts.bias.data_ptr()
+    p.act = act
+    p.act_param = act_param
+    p.alpha = alpha
+    p.beta = beta
+    p4 = (wts.cout + 3) // 4
+    for name, r in (('res1', res1), ('res2', res2), ('out_f32', out_f32)):
+        if r is not None:
+            if tuple(r.shape) != (x.n, p4, H, W, 4) or r.dtype != torch.float32 or not r.is_contiguous():
+                raise ValueError(f'{name} must be a contiguous f32 [N,{p4},{H},{W},4] map, got {tuple(r.shape)} {r.dtype}')
+    p.res1 = None if res1 is None else res1.data_ptr()
+    p.res2 = None if res2 is None else res2.data_ptr()
+    p.out_f32 = None if out_f32 is None else out_f32.data_ptr()
+    nplanes_out = (wts.cout + 7) // 8
+    if out is not None:
+        if (out.h, out.w, out.n) != (H, W, x.n) or out_plane_off + nplanes_out > out.planes:
+            raise ValueError('output planes do not match the convolution output')
+        p.out_hi = out.hi_ptr()
+        p.out_lo = out.lo_ptr()
+        p.out_plane_off = out_plane_off
+        p.out_plane_stride = out.plane_stride
+        p.out_batch_stride = out.batch_stride
+    if pre is not None:
+        if (pre.h, pre.w, pre.n) != (H, W, x.n) or pre_plane_off + nplanes_out > pre.planes:
+            raise ValueError('pre-activation planes do not match the convolution output')
+        p.pre_hi = pre.hi_ptr()
+        p.pre_lo = pre.lo_ptr()
+        p.pre_plane_off = pre_plane_off
+        p.pre_plane_stride = pre.plane_stride
+        p.pre_batch_stride = pre.batch_stride
+    p.pixel_shuffle = pixel_shuffle
+    p.out_scale = out_scale
+    if out_nchw is not None:
+        r = max(pixel_shuffle, 1)
+        exp = (x.n, wts.cout // (r * r), H * r, W * r)
+        if tuple(out_nchw.shape) != exp or not out_nchw.is_contiguous():
+            raise ValueError(f'out_nchw must be contiguous {exp}, got {tuple(out_nchw.shape)}')
+        p.out_nchw = out_nchw.data_ptr()
+        p.out_dtype = rsa_dtype(out_nchw.dtype)
+        p.out_shift = None if out_shift is None else out_shift.data_ptr()
+    return p
+
+
+def run_convs(params: list[L.ConvParams], device) -> None:
+    L.conv2d_list(params, current_stream_ptr(device))
+
+
+def nchw_to_planes(x: torch.Tensor, out: Planes, mean: torch.Tensor | None = None, scale: float = 1.0) -> None:
+    """Plain [N,C,H,W] tensor -> split planes on the GPU (rsa_nchw_to_planes)."""
+    require_cuda(x, 'nchw_to_planes')
+    if not x.is_contiguous():
+        x = x.contiguous()
+    n, c, h, w = x.shape
+    if (out.n, out.h, out.w) != (n, h, w) or out.planes < (c + 7) // 8:
+        raise ValueError('output planes do not match the input tensor')
+    lib = L.load()
+    L.check(
+        lib.rsa_nchw_to_planes(
+            x.data_ptr(), rsa_dtype(x.dtype), n, c, h, w, None if mean is None else mean.data_ptr(), scale,
+            out.hi_ptr(), out.lo_ptr(), out.plane_stride, out.batch_stride, C.c_void_p(current_stream_ptr(x.device)),
+        ),
+        'rsa_nchw_to_planes',
+    )  # fmt: skip
+
+
+def planes_to_nchw(p: Planes, channels: int) -> torch.Tensor:
+    """Split planes -> f32 [N,C,H,W] on the GPU (rsa_planes_to_nchw); for parity checks of intermediates."""
+    out = torch.empty((p.n, channels, p.h, p.w), dtype=torch.float32, device=p.hi.device)
+    lib = L.load()
+    L.check(
+        lib.rsa_planes_to_nchw(
+            p.hi_ptr(), p.lo_ptr(), p.plane_stride, p.batch_stride, p.n, channels, p.h, p.w, out.data_ptr(),
+            C.c_void_p(current_stream_ptr(out.device)),
+        ),
+        'rsa_planes_to_nchw',
+    )  # fmt: skip
+    return out

@@ -1,0 +1,194 @@
+"""GPU parity of the fused convolution kernel (C-ABI rsa_conv2d_list) against torch CPU fp32.
+
+Tolerances: products=3 (split bf16, ~16-bit operands) is checked at 2e-5 * scale, products=1
+(plain bf16 operands) at 1.5e-2 * scale, where scale = max|reference|.
+"""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from resselt_amd.engine import lib as L
+from resselt_amd.engine import ops, tensors
+
+pytestmark = pytest.mark.gpu
+
+TOL = {3: 2e-5, 1: 1.5e-2}
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def _ref_conv(x, w, b, up=False):
+    if up:
+        x = F.interpolate(x, scale_factor=2, mode='nearest')
+    return F.conv2d(x, w, b, padding=w.shape[-1] // 2)
+
+
+def _check(got, ref, products, what):
+    scale = ref.abs().max().item()
+    err = (got.cpu() - ref).abs().max().item()
+    assert err <= TOL[products] * max(scale, 1e-6), f'{what}: max-abs {err:.3e} vs scale {scale:.3e}'
+
+
+@pytest.mark.parametrize('products', [3, 1])
+@pytest.mark.parametrize(
+    'n,cin,cout,h,w,k',
+    [
+        (2, 64, 32, 20, 45, 3),  # ragged tile edges, two tiles in x
+        (1, 192, 64, 9, 33, 3),  # deepest RDB conv
+        (1, 3, 64, 16, 32, 3),  # first conv, channel padding 3 -> 8
+        (1, 64, 3, 17, 31, 3),  # last conv, cout padding
+        (1, 192, 48, 8, 40, 1),  # SPAN conv_cat (k1)
+        (1, 240, 720, 8, 32, 1),  # SwinIR qkv linear: several cout slabs
+        (1, 48, 48, 24, 24, 3),  # SPAN width: half-filled last K chunk
+    ],
+)
+def test_conv_plain(device, products, n, cin, cout, h, w, k):
+    x = _rand((n, cin, h, w), 1)
+    wt = _rand((cout, cin, k, k), 2, 1.0 / (cin * k * k) ** 0.5)
+    b = _rand((cout,), 3, 0.1)
+    ref = _ref_conv(x, wt, b)
+    wts = ops.ConvWeights.from_oihw(wt, b, products, device=device)
+    xin = tensors.nchw_to_planes(x.to(device), with_lo=True)
+    out = tensors.Planes.empty(n, (cout + 7) // 8, h, w, device)
+    of32 = tensors.empty_f32map(n, cout, h, w, device)
+    onchw = torch.empty((n, cout, h, w), dtype=torch.float32, device=device)
+    p = ops.conv_params(wts, xin, h, w, out=out, out_f32=of32, out_nchw=onchw)
+    ops.run_convs([p], device)
+    torch.cuda.synchronize()
+    _check(onchw, ref, products, 'out_nchw')
+    _check(tensors.f32map_to_nchw(of32, cout), ref, products, 'out_f32')
+    # split planes hold ~16 bits: compare at the looser of the two tolerances
+    got = tensors.planes_to_nchw(out, cout)
+    scale = ref.abs().max().item()
+    assert (got.cpu() - ref).abs().max().item() <= max(TOL[products], 1e-5) * scale * 1.5
+    # channels padded up to the plane boundary must be exact zeros
+    full = tensors.planes_to_nchw(out, out.planes * 8)
+    if out.planes * 8 > cout:
+        assert full[:, cout:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize('products', [3, 1])
+def test_conv_rdb_epilogue(device, products):
+    """conv5 of the last RDB of an RRDB: (acc*0.2 + x)*0.2 + x0, virtual concat input, plane-offset output."""
+    n, h, w = 1, 19, 37
+    x = _rand((n, 192, h, w), 5)
+    wt = _rand((64, 192, 3, 3), 6, 1.0 / (192 * 9) ** 0.5)
+    b = _rand((64,), 7, 0.1)
+    r1 = _rand((n, 64, h, w), 8)
+    r2 = _rand((n, 64, h, w), 9)
+    ref = (_ref_conv(x, wt, b) * 0.2 + r1) * 0.2 + r2
+    wts = ops.ConvWeights.from_oihw(wt, b, products, device=device)
+    # input lives at plane offset 3 of a wider buffer (virtual concat / workspace reuse)
+    big = tensors.Planes.empty(n, 30, h, w, device)
+    big.hi.zero_()
+    big.lo.zero_()
+    src = tensors.nchw_to_planes(x.to(device))
+    big.hi[:, 3:27] = src.hi
+    big.lo[:, 3:27] = src.lo
+    out = tensors.Planes.empty(n, 12, h, w, device)
+    out.hi.fill_(7.0)
+    out.lo.fill_(7.0)
+    of32 = tensors.empty_f32map(n, 64, h, w, device)
+    p = ops.conv_params(
+        wts, big, h, w, in_plane0=3, res1=tensors.nchw_to_f32map(r1.to(device)), alpha=0.2,
+        res2=tensors.nchw_to_f32map(r2.to(device)), beta=0.2, out=out, out_plane_off=4, out_f32=of32,
+    )  # fmt: skip
+    ops.run_convs([p], device)
+    torch.cuda.synchronize()
+    _check(tensors.f32map_to_nchw(of32, 64), ref, products, 'rdb epilogue f32')
+    got = tensors.planes_to_nchw(tensors.Planes(out.hi[:, 4:12].contiguous(), out.lo[:, 4:12].contiguous()), 64)
+    assert (got.cpu() - ref).abs().max().item() <= max(TOL[products], 1e-5) * ref.abs().max().item() * 1.5
+    # planes outside [4,12) untouched
+    assert torch.all(out.hi[:, :4].float() == 7.0) and torch.all(out.lo[:, :4].float() == 7.0)
+
+
+@pytest.mark.parametrize('products', [3, 1])
+def test_conv_upsample_lrelu(device, products):
+    """upconv_block: nearest x2 fused into the read, LeakyReLU(0.2) epilogue."""
+    n, h, w = 1, 11, 21
+    x = _rand((n, 64, h, w), 11)
+    wt = _rand((64, 64, 3, 3), 12, 1.0 / (64 * 9) ** 0.5)
+    b = _rand((64,), 13, 0.1)
+    ref = F.leaky_relu(_ref_conv(x, wt, b, up=True), 0.2)
+    wts = ops.ConvWeights.from_oihw(wt, b, products, device=device)
+    xin = tensors.nchw_to_planes(x.to(device))
+    onchw = torch.empty((n, 64, 2 * h, 2 * w), dtype=torch.float32, device=device)
+    p = ops.conv_params(wts, xin, 2 * h, 2 * w, upsample2x=True, act=L.ACT_LRELU, act_param=0.2, out_nchw=onchw)
+    ops.run_convs([p], device)
+    torch.cuda.synchronize()
+    _check(onchw, ref, products, 'upconv')
+
+
+@pytest.mark.parametrize('act,fn', [(L.ACT_MISH, F.mish), (L.ACT_SILU, F.silu), (L.ACT_GELU, F.gelu)])
+def test_conv_activations_and_pre(device, act, fn):
+    n, h, w = 1, 13, 18
+    x = _rand((n, 48, h, w), 21, 2.0)
+    wt = _rand((48, 48, 3, 3), 22, 3.0 / (48 * 9) ** 0.5)
+    b = _rand((48,), 23, 0.5)
+    pre_ref = _ref_conv(x, wt, b)
+    ref = fn(pre_ref)
+    wts = ops.ConvWeights.from_oihw(wt, b, 3, device=device)
+    xin = tensors.nchw_to_planes(x.to(device))
+    pre = tensors.Planes.empty(n, 6, h, w, device)
+    onchw = torch.empty((n, 48, h, w), dtype=torch.float32, device=device)
+    p = ops.conv_params(wts, xin, h, w, act=act, pre=pre, out_nchw=onchw)
+    ops.run_convs([p], device)
+    torch.cuda.synchronize()
+    _check(onchw, ref, 3, 'activation')
+    got = tensors.planes_to_nchw(pre, 48)
+    assert (got.cpu() - pre_ref).abs().max().item() <= 3e-5 * pre_ref.abs().max().item()
+
+
+def test_conv_spab_gate_and_pixelshuffle(device):
+    n, h, w = 2, 10, 35
+    x = _rand((n, 48, h, w), 31)
+    wt = _rand((48, 48, 3, 3), 32, 2.0 / (48 * 9) ** 0.5)
+    b = _rand((48,), 33, 0.2)
+    skip = _rand((n, 48, h, w), 34)
+    o3 = _ref_conv(x, wt, b)
+    ref = (o3 + skip) * (torch.sigmoid(o3) - 0.5)
+    wts = ops.ConvWeights.from_oihw(wt, b, 3, device=device)
+    xin = tensors.nchw_to_planes(x.to(device))
+    of32 = tensors.empty_f32map(n, 48, h, w, device)
+    p = ops.conv_params(wts, xin, h, w, act=L.ACT_SPAB_GATE, res1=tensors.nchw_to_f32map(skip.to(device)), out_f32=of32)
+    ops.run_convs([p], device)
+    torch.cuda.synchronize()
+    _check(tensors.f32map_to_nchw(of32, 48), ref, 3, 'spab gate')
+    # conv -> PixelShuffle(4) with an output affine, stored as fp16
+    wt2 = _rand((48, 48, 3, 3), 35, 1.0 / (48 * 9) ** 0.5)
+    ref2 = F.pixel_shuffle(_ref_conv(x, wt2, None), 4) * 0.5 + torch.tensor([0.1, 0.2, 0.3]).view(1, 3, 1, 1)
+    wts2 = ops.ConvWeights.from_oihw(wt2, None, 3, device=device)
+    o16 = torch.empty((n, 3, 4 * h, 4 * w), dtype=torch.float16, device=device)
+    shift = torch.tensor([0.1, 0.2, 0.3], device=device)
+    p2 = ops.conv_params(wts2, xin, h, w, out_nchw=o16, pixel_shuffle=4, out_scale=0.5, out_shift=shift)
+    ops.run_convs([p2], device)
+    torch.cuda.synchronize()
+    assert (o16.float().cpu() - ref2).abs().max().item() <= 2e-3
+
+
+def test_layout_kernels(device):
+    x = _rand((2, 5, 7, 9), 41)
+    mean = torch.tensor([0.1, 0.2, 0.3, 0.4, 0.5])
+    out = tensors.Planes.empty(2, 1, 7, 9, device)
+    ops.nchw_to_planes(x.to(device), out, mean.to(device), 255.0)
+    back = ops.planes_to_nchw(out, 8)
+    torch.cuda.synchronize()
+    ref = (x - mean.view(1, 5, 1, 1)) * 255.0
+    assert (back[:, :5].cpu() - ref).abs().max().item() <= 2e-5 * 255
+    assert back[:, 5:].abs().max().item() == 0.0
+    xh = x.half().to(device)
+    ops.nchw_to_planes(xh, out)
+    assert (ops.planes_to_nchw(out, 5).cpu() - xh.float().cpu()).abs().max().item() <= 1e-5
+
+
+def test_argument_errors(device):
+    wts = ops.ConvWeights.from_oihw(torch.zeros(8, 8, 3, 3), None, 3, device=device)
+    xin = tensors.Planes.empty(1, 1, 8, 8, device)
+    p = ops.conv_params(wts, xin, 8, 8)
+    p.ksize = 5
+    with pytest.raises(RuntimeError, match='ksize'):
+        ops.run_convs([p], device)
