@@ -85,7 +85,7 @@ typedef struct rsa_conv_params {
   int64_t in_plane_stride;  /* units between planes  (= Hin*Win for a dense tensor) */
   int64_t in_batch_stride;  /* units between images  */
 
-  /* weights packed by rsa_pack_conv_weights_host layout, bias f32[cout_pad] */
+  /* weights in the packed layout described below (resselt_amd/engine/pack.py), bias f32[round_up(cout,16)] */
   const void* w_packed;
   const float* bias; /* may be NULL */
 
@@ -104,11 +104,6 @@ typedef struct rsa_conv_params {
   int64_t out_plane_stride; /* units */
   int64_t out_batch_stride; /* units */
   float* out_f32;           /* f32 NCHW4c residual stream */
-  void* pre_hi;             /* optional: PRE-activation value as split planes (SPAB `out1`, */
-  void* pre_lo;             /*   archs/spanplus/arch.py:118,128-129), same strides/off as out_* */
-  int32_t pre_plane_off;
-  int64_t pre_plane_stride;
-  int64_t pre_batch_stride;
 
   void* out_nchw;           /* final plain tensor [N][cout/r^2][H*r][W*r], dtype out_dtype */
   int32_t out_dtype;        /* enum rsa_dtype */
@@ -123,6 +118,10 @@ int rsa_conv2d_list(const rsa_conv_params* list, int32_t n, void* stream);
 
 /* Bytes of the packed weight blob for a (cout, cin_planes, ksize, products) convolution. */
 int64_t rsa_packed_weight_bytes(int32_t cout, int32_t cin_planes, int32_t ksize, int32_t products);
+
+/* Number of 16-channel cout tiles one workgroup computes for `cout` output channels (1..4); the grid has
+ * ceil(ceil(cout/16) / tiles) slabs in y.  Exposed so host code and tests can reason about launch geometry. */
+int rsa_conv_cout_tiles(int32_t cout);
 
 /*
  * Weight packing happens on the host side of the boundary (resselt_amd/engine/pack.py,

@@ -38,9 +38,15 @@ def conv3xc(sd: Mapping[str, torch.Tensor], prefix: str, x: torch.Tensor) -> tor
 
 
 def spab(sd, prefix: str, x: torch.Tensor, act) -> tuple[torch.Tensor, torch.Tensor]:
-    """SPAB.forward (spanplus/arch.py:117-130, span/arch.py:167-180); returns (out, out1)."""
-    out1 = conv3xc(sd, f'{prefix}.c1_r', x)
-    out2 = conv3xc(sd, f'{prefix}.c2_r', act(out1))
+    """SPAB.forward (spanplus/arch.py:117-130, span/arch.py:167-180); returns (out, out1).
+
+    The reference's activation is IN-PLACE (``nn.Mish(inplace=True)`` spanplus/arch.py:114, ``nn.SiLU(inplace=True)``
+    span/arch.py:164), so by the time ``out1`` is returned (``end=True``) it aliases the *activated* tensor:
+    the value concatenated into ``conv_cat`` is act(c1_r(x)), not the pre-activation (pinned by
+    tests/golden/blocks_span.npz ``spab_out1``).
+    """
+    out1 = act(conv3xc(sd, f'{prefix}.c1_r', x))
+    out2 = conv3xc(sd, f'{prefix}.c2_r', out1)
     out3 = conv3xc(sd, f'{prefix}.c3_r', act(out2))
     return (out3 + x) * (torch.sigmoid(out3) - 0.5), out1
 

@@ -1,0 +1,12 @@
+"""Architectures served by the MI355X engine, registered explicitly in detection order.
+
+The reference discovers 31 architectures by walking the filesystem (``resselt/archs/__init__.py:11-28``);
+this build registers the families of the hot path: ESRGAN/RRDBNet, SPANPlus, SPAN, SwinIR.
+"""
+
+from ..registry import Registry
+from .esrgan import ESRGANArch
+
+internal_registry = Registry()
+for _arch in (ESRGANArch,):
+    internal_registry.add(_arch())

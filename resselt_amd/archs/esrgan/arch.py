@@ -1,0 +1,233 @@
+"""RRDBNet (ESRGAN / BSRGAN / Real-ESRGAN) on the MI355X engine.
+
+Reference module: ``resselt/archs/esrgan/arch.py:12-138`` with blocks from ``resselt/utilities/block.py``
+(RRDB :277-344, ResidualDenseBlock_5C :347-465, upconv_block :510-537).  The parameter names are the
+reference's old-arch names; the forward pass is the launch list below instead of 351 ``nn.Conv2d`` calls,
+276 ``torch.cat`` copies and two ``nn.Upsample`` materialisations:
+
+  * dense concatenation = plane offsets into one 24-plane (nf + 4*gc channels) workspace per RDB;
+  * LeakyReLU, ``x5*0.2 + x``, ``out*0.2 + x`` (RRDB) and the trunk shortcut are conv epilogues
+    (the residual stream stays f32, the conv operands are split bf16);
+  * nearest x2 is folded into the read of the following convolution.
+"""
+
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from ...engine import lib as L
+from ...engine import ops
+from ...engine.base import EngineModule, Plan
+from ...engine.paramtree import build_param_tree
+
+_GC = 32  # growth channels are fixed by the reference ctor (arch.py:88)
+
+
+def rrdbnet_param_shapes(in_nc, out_nc, nf, nb, scale, plus) -> dict:
+    shapes: dict = {}
+
+    def conv(name, cout, cin, k=3, bias=True):
+        shapes[f'{name}.weight'] = (cout, cin, k, k)
+        if bias:
+            shapes[f'{name}.bias'] = (cout,)
+
+    conv('model.0', nf, in_nc)
+    for i in range(nb):
+        for r in (1, 2, 3):
+            p = f'model.1.sub.{i}.RDB{r}'
+            if plus:
+                conv(f'{p}.conv1x1', _GC, nf, 1, bias=False)
+            for j in range(1, 6):
+                conv(f'{p}.conv{j}.0', _GC if j < 5 else nf, nf + (j - 1) * _GC)
+    conv(f'model.1.sub.{nb}', nf, nf)
+    k = 3
+    for _ in range(int(math.log2(scale))):
+        conv(f'model.{k}', nf, nf)
+        k += 3
+    k -= 1
+    conv(f'model.{k}', nf, nf)
+    conv(f'model.{k + 2}', out_nc, nf)
+    return shapes
+
+
+def new_arch_to_old(state_dict) -> dict:
+    """Official Real-ESRGAN / BSRGAN key spellings -> the old-arch names this module owns.
+
+    Same mapping as the reference's ``_to_old_arch`` (resselt/archs/esrgan/__init__.py:14-121); unlike the
+    reference's registry, the converted dict is what actually gets loaded (SURVEY.md §3.1 deviation).
+    """
+    if 'conv_first.weight' not in state_dict:
+        return state_dict
+    body_keys = [k for k in state_dict if k.startswith(('body.', 'RRDB_trunk.'))]
+    nb = 1 + max(int(k.split('.')[1]) for k in body_keys)
+    ups = sorted({int(k.split('.')[0][-1]) for k in state_dict if k.startswith(('upconv', 'conv_up'))})
+    hr_index = (max(ups) * 3 if ups else 0) + 2
+    out = {}
+    for key, value in state_dict.items():
+        head, _, kind = key.rpartition('.')
+        if head == 'conv_first':
+            new = f'model.0.{kind}'
+        elif head in ('conv_body', 'trunk_conv'):
+            new = f'model.1.sub.{nb}.{kind}'
+        elif head.startswith(('body.', 'RRDB_trunk.')):
+            _, blk, rdb, conv = head.split('.')
+            new = f'model.1.sub.{blk}.RDB{rdb[-1]}.{conv}.0.{kind}'
+        elif head.startswith(('upconv', 'conv_up')):
+            new = f'model.{int(head[-1]) * 3}.{kind}'
+        elif head in ('HRconv', 'conv_hr'):
+            new = f'model.{hr_index}.{kind}'
+        elif head == 'conv_last':
+            new = f'model.{hr_index + 2}.{kind}'
+        else:
+            new = key
+        out[new] = value
+    return out
+
+
+class RRDBNet(EngineModule):
+    hyperparameters = {}
+
+    def __init__(self, in_nc: int = 3, out_nc: int = 3, num_filters: int = 64, num_blocks: int = 23, scale: int = 4,
+                 plus: bool = False, shuffle_factor: int | None = None) -> None:  # fmt: skip
+        super().__init__()
+        if scale not in (1, 2, 4, 8):
+            raise NotImplementedError(f'RRDBNet engine supports power-of-two scales, got {scale}')
+        if num_filters % 8:
+            raise NotImplementedError('num_filters must be a multiple of 8')
+        self.in_nc, self.out_nc, self.nf, self.nb = in_nc, out_nc, num_filters, num_blocks
+        self.net_scale = scale  # upsampling done by the conv stack
+        self.plus = plus
+        self.shuffle_factor = shuffle_factor
+        self.scale = scale // shuffle_factor if shuffle_factor else scale
+        build_param_tree(self, rrdbnet_param_shapes(in_nc, out_nc, num_filters, num_blocks, scale, plus))
+
+    def _convert_state_dict(self, state_dict):
+        return new_arch_to_old(state_dict)
+
+    def macs_per_input_pixel(self) -> int:
+        """Algorithmic multiply-accumulates per pixel of the network input grid (SURVEY.md §8d counts these)."""
+        total, res = 0, 1
+        n_up = int(math.log2(self.net_scale))
+        first_up = 3
+        for name, w in self.state_dict().items():
+            if not name.endswith('.weight'):
+                continue
+            parts = name.split('.')
+            if parts[1] not in ('0', '1'):
+                idx = int(parts[1])
+                ups_done = min(n_up, (idx - first_up) // 3 + 1) if idx >= first_up else 0
+                res = 4**ups_done
+            total += w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3] * res
+        return total
+
+    # ---------------------------------------------------------------- weights
+    def _pack(self, device, products):
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        out = {}
+        for name in sd:
+            if name.endswith('.weight'):
+                base = name[: -len('.weight')]
+                out[base] = ops.ConvWeights.from_oihw(sd[name], sd.get(f'{base}.bias'), products, device=device)
+        return out
+
+    # ---------------------------------------------------------------- plan
+    def _build_plan(self, plan: Plan, W, x_shape, dtype, products):
+        n, c, h_in, w_in = x_shape
+        sf = self.shuffle_factor
+        if sf:
+            # pixel-unshuffle front (arch.py:130-137): reflect-pad to a multiple, fold s x s pixels into channels
+            pad_h, pad_w = (sf - h_in % sf) % sf, (sf - w_in % sf) % sf
+            h, w = (h_in + pad_h) // sf, (w_in + pad_w) // sf
+            c_net = c * sf * sf
+        else:
+            pad_h = pad_w = 0
+            h, w, c_net = h_in, w_in, c
+        if c_net != self.in_nc:
+            raise RuntimeError(f'model expects {self.in_nc // (sf * sf if sf else 1)} input channels, got {c}')
+        nf, nb, gc = self.nf, self.nb, _GC
+        with_lo = products == 3
+        pf, pg = nf // 8, gc // 8
+        x_pl = plan.planes(n, (c_net + 7) // 8, h, w, with_lo)
+        ws = [plan.planes(n, pf + 4 * pg, h, w, with_lo) for _ in range(2)]
+        fea = plan.f32map(n, nf, h, w)
+        pool = [plan.f32map(n, nf, h, w) for _ in range(4)]
+        lrelu = dict(act=L.ACT_LRELU, act_param=0.2)
+
+        holder = {}
+
+        def set_input(x):
+            if sf:
+                x = F.pixel_unshuffle(F.pad(x, (0, pad_w, 0, pad_h), 'reflect'), sf)
+            holder['x'] = x
+            ops.nchw_to_planes(x, x_pl)
+
+        # fea conv (arch.py:74-80): split planes into workspace 0 and the f32 residual stream
+        plan.conv(ops.conv_params(W['model.0'], x_pl, h, w, out=ws[0], out_plane_off=0, out_f32=fea))
+        cur_f32, cur_ws = fea, 0
+        free = list(pool)
+        c11 = plan.f32map(n, gc, h, w) if self.plus else None
+        x2_f32 = plan.f32map(n, gc, h, w) if self.plus else None
+        for i in range(nb):
+            rrdb_in = cur_f32
+            taken = []
+            for r in (1, 2, 3):
+                p = f'model.1.sub.{i}.RDB{r}'
+                a, b = ws[cur_ws], ws[cur_ws ^ 1]
+                for j in range(1, 5):
+                    kw = dict(cin_planes=pf + (j - 1) * pg, out=a, out_plane_off=pf + (j - 1) * pg, **lrelu)
+                    if self.plus and j == 2:
+                        # ESRGAN+ (block.py:457-463): x2 = lrelu(conv2) + conv1x1(x); x4 = lrelu(conv4) + x2
+                        plan.conv(ops.conv_params(W[f'{p}.conv1x1'], a, h, w, cin_planes=pf, out_f32=c11))
+                        kw.update(res1=c11, alpha=1.0, out_f32=x2_f32)
+                    if self.plus and j == 4:
+                        kw.update(res1=x2_f32, alpha=1.0)
+                    plan.conv(ops.conv_params(W[f'{p}.conv{j}.0'], a, h, w, **kw))
+                nxt = free.pop()
+                taken.append(nxt)
+                kw = dict(cin_planes=pf + 4 * pg, res1=cur_f32, alpha=0.2, out=b, out_plane_off=0, out_f32=nxt)
+                if r == 3:
+                    kw.update(res2=rrdb_in, beta=0.2)  # RRDB.forward: out*0.2 + x (block.py:340-344)
+                plan.conv(ops.conv_params(W[f'{p}.conv5.0'], a, h, w, **kw))
+                cur_f32, cur_ws = nxt, cur_ws ^ 1
+            # recycle f32 maps: everything except the RRDB output
+            if rrdb_in is not fea:
+                free.append(rrdb_in)
+            free.extend(taken[:2])
+        # trunk conv + ShortcutBlock (block.py:83-91)
+        u = plan.planes(n, pf, h, w, with_lo)
+        plan.conv(ops.conv_params(W[f'model.1.sub.{nb}'], ws[cur_ws], h, w, cin_planes=pf, res1=fea, alpha=1.0, out=u))
+        k = 3
+        hh, wwid = h, w
+        for _ in range(int(math.log2(self.net_scale))):
+            hh, wwid = hh * 2, wwid * 2
+            nu = plan.planes(n, pf, hh, wwid, with_lo)
+            plan.conv(ops.conv_params(W[f'model.{k}'], u, hh, wwid, upsample2x=True, out=nu, **lrelu))
+            u = nu
+            k += 3
+        k -= 1
+        hr = plan.planes(n, pf, hh, wwid, with_lo)
+        plan.conv(ops.conv_params(W[f'model.{k}'], u, hh, wwid, out=hr, **lrelu))
+        out_buf = {'y': torch.empty((n, self.out_nc, hh, wwid), dtype=dtype, device=plan.device)}
+        plan.conv(ops.conv_params(W[f'model.{k + 2}'], hr, hh, wwid, out_nchw=out_buf['y']))
+        arr = plan.flush()
+        last_entry = arr[len(arr) - 1]
+
+        # a fresh output tensor per call: patch the last descriptor's pointer before launching
+        def prepare_output():
+            if 'y' not in out_buf:
+                out_buf['y'] = torch.empty((n, self.out_nc, hh, wwid), dtype=dtype, device=plan.device)
+            last_entry.out_nchw = out_buf['y'].data_ptr()
+
+        plan.steps.insert(len(plan.steps) - 1, prepare_output)
+
+        def get_output():
+            y = out_buf.pop('y')
+            holder.clear()
+            if sf:
+                y = y[:, :, : h_in * self.scale, : w_in * self.scale]
+            return y
+
+        return set_input, get_output

@@ -268,13 +268,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_kernel(const rsa_conv_params
         float b = (p.bias != nullptr && c < p.cout) ? p.bias[c] : 0.f;
         v[r] = acc[pt][ct][r] + b;
       }
-      if (p.pre_hi != nullptr) {
-        float z[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) z[r] = (c0 + r < p.cout) ? v[r] : 0.f;
-        const int64_t unit = (int64_t)n * p.pre_batch_stride + (int64_t)(p.pre_plane_off + (c0 >> 3)) * p.pre_plane_stride + pix;
-        split_store(p.pre_hi, p.pre_lo, unit, (c0 >> 2) & 1, z);
-      }
       const bool has_f32grp = c0 < (p4 << 2);
       const int64_t f32idx = (((int64_t)n * p4 + (c0 >> 2)) * HW + pix);
       if (p.act == RSA_ACT_SPAB_GATE) {
@@ -380,7 +373,7 @@ int conv_launch(const rsa_conv_params& p, hipStream_t stream) {
   if (p.act == RSA_ACT_SPAB_GATE && p.res1 == nullptr) return set_error(RSA_E_ARG, "conv: SPAB gate needs res1");
   if (p.act < 0 || p.act > RSA_ACT_SPAB_GATE) return set_error(RSA_E_ARG, "conv: bad act");
   if (((uintptr_t)p.in_hi | (uintptr_t)p.in_lo | (uintptr_t)p.w_packed | (uintptr_t)p.out_hi | (uintptr_t)p.out_lo | (uintptr_t)p.out_f32 |
-       (uintptr_t)p.res1 | (uintptr_t)p.res2 | (uintptr_t)p.pre_hi | (uintptr_t)p.pre_lo) & 15)
+       (uintptr_t)p.res1 | (uintptr_t)p.res2) & 15)
     return set_error(RSA_E_ALIGN, "conv: pointers must be 16-byte aligned");
   if (p.in_plane_stride * 4 >= (int64_t)1 << 32) return set_error(RSA_E_UNSUPPORTED, "conv: input plane too large for 32-bit unit offsets; band the image");
   if (p.out_nchw != nullptr) {

@@ -1,0 +1,164 @@
+"""Common machinery of the engine-backed models returned by the loaders.
+
+An ``EngineModule`` is an ``nn.Module`` that *owns parameters under the reference's key names* (so the
+registry's strict ``load_state_dict`` and the usual ``.to()/.half()/.state_dict()`` work) but whose
+``forward`` is a cached *plan*: device buffers in the engine's layouts plus an array of C-ABI launch
+descriptors that ``rsa_conv2d_list`` executes with one host call.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable
+
+import torch
+from torch import nn
+
+from . import lib as L
+from . import ops
+from .tensors import Planes, empty_f32map
+
+PRECISIONS = {'bf16x3': 3, 'bf16': 1}
+
+
+class Plan:
+    """Buffers + launch list for one (batch, H, W, dtype, device, precision) signature."""
+
+    def __init__(self, device):
+        self.device = device
+        self.keep: list[object] = []  # tensors referenced by raw pointer in the descriptors
+        self.steps: list[Callable[[], None]] = []  # executed in order on the current stream
+        self._pending: list[L.ConvParams] = []
+
+    # ---- buffers ----
+    def planes(self, n, planes, h, w, with_lo=True) -> Planes:
+        p = Planes.empty(n, planes, h, w, self.device, with_lo)
+        self.keep.append(p)
+        return p
+
+    def f32map(self, n, channels, h, w) -> torch.Tensor:
+        t = empty_f32map(n, channels, h, w, self.device)
+        self.keep.append(t)
+        return t
+
+    # ---- launch list ----
+    def conv(self, params: L.ConvParams) -> L.ConvParams:
+        self._pending.append(params)
+        return params
+
+    def flush(self) -> 'C.Array | None':
+        """Close the current run of convolutions into one ``rsa_conv2d_list`` step."""
+        if not self._pending:
+            return None
+        arr = (L.ConvParams * len(self._pending))(*self._pending)
+        self._n_launches = getattr(self, '_n_launches', 0) + len(self._pending)
+        self._pending = []
+        dev = self.device
+        self.steps.append(lambda: L.conv2d_list(arr, ops.current_stream_ptr(dev)))
+        return arr
+
+    def call(self, fn: Callable[[], None]) -> None:
+        self.flush()
+        self.steps.append(fn)
+
+    def run(self) -> None:
+        self.flush()
+        for step in self.steps:
+            step()
+
+    def n_launches(self) -> int:
+        return getattr(self, '_n_launches', 0)
+
+    def buffer_bytes(self) -> int:
+        total = 0
+        for k in self.keep:
+            if isinstance(k, Planes):
+                total += k.hi.numel() * 2 * (2 if k.lo is not None else 1)
+            elif isinstance(k, torch.Tensor):
+                total += k.numel() * k.element_size()
+        return total
+
+
+class EngineModule(nn.Module):
+    """Base of the MI355X models.  Subclasses implement ``_pack`` and ``_build_plan``."""
+
+    def __init__(self):
+        super().__init__()
+        self.precision: str = 'bf16x3'
+        self._packed: dict = {}
+        self._plans: dict = {}
+        self._max_plans = 4
+
+    # -- cache invalidation: anything that can change parameter values, dtype or device --
+    def _invalidate(self) -> None:
+        self._packed = {}
+        self._plans = {}
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        result = super().load_state_dict(self._convert_state_dict(state_dict), strict=strict, assign=assign)
+        self._invalidate()
+        return result
+
+    def _convert_state_dict(self, state_dict):
+        return state_dict
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        self._invalidate()
+        return out
+
+    def launches_per_forward(self) -> int | None:
+        """Kernel launches of the most recently built plan (None before the first forward)."""
+        if not self._plans:
+            return None
+        return list(self._plans.values())[-1][0].n_launches()
+
+    @property
+    def products(self) -> int:
+        try:
+            return PRECISIONS[self.precision]
+        except KeyError:
+            raise ValueError(f'precision must be one of {sorted(PRECISIONS)}, got {self.precision!r}') from None
+
+    # -- hooks --
+    def _pack(self, device, products: int):
+        raise NotImplementedError
+
+    def _build_plan(self, plan: Plan, packed, x_shape, dtype, products: int):
+        """Return (input_setter, output_getter)."""
+        raise NotImplementedError
+
+    def _weights(self, device):
+        key = (str(device), self.products)
+        w = self._packed.get(key)
+        if w is None:
+            with torch.no_grad():
+                w = self._pack(device, self.products)
+            self._packed = {key: w}
+            self._plans = {}
+        return w
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        ops.require_cuda(x, type(self).__name__)
+        if x.dim() != 4:
+            raise ValueError(f'expected a [N, C, H, W] tensor, got shape {tuple(x.shape)}')
+        ops.rsa_dtype(x.dtype)  # raises for unsupported dtypes
+        first = next(self.parameters(), None)
+        if first is not None and first.device != x.device:
+            raise RuntimeError(f'model parameters are on {first.device} but the input is on {x.device}')
+        packed = self._weights(x.device)
+        key = (tuple(x.shape), x.dtype, str(x.device), self.products)
+        entry = self._plans.get(key)
+        if entry is None:
+            if len(self._plans) >= self._max_plans:
+                self._plans.pop(next(iter(self._plans)))
+            plan = Plan(x.device)
+            set_input, get_output = self._build_plan(plan, packed, tuple(x.shape), x.dtype, self.products)
+            plan.flush()
+            entry = (plan, set_input, get_output)
+            self._plans[key] = entry
+        plan, set_input, get_output = entry
+        with torch.cuda.device(x.device):
+            set_input(x.contiguous())
+            plan.run()
+            return get_output()

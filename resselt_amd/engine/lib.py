@@ -50,11 +50,6 @@ class ConvParams(C.Structure):
         ('out_plane_stride', C.c_int64),
         ('out_batch_stride', C.c_int64),
         ('out_f32', C.c_void_p),
-        ('pre_hi', C.c_void_p),
-        ('pre_lo', C.c_void_p),
-        ('pre_plane_off', C.c_int32),
-        ('pre_plane_stride', C.c_int64),
-        ('pre_batch_stride', C.c_int64),
         ('out_nchw', C.c_void_p),
         ('out_dtype', C.c_int32),
         ('pixel_shuffle', C.c_int32),

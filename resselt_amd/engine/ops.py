@@ -75,8 +75,6 @@ def conv_params(
     out: Planes | None = None,
     out_plane_off: int = 0,
     out_f32: torch.Tensor | None = None,
-    pre: Planes | None = None,
-    pre_plane_off: int = 0,
     out_nchw: torch.Tensor | None = None,
     pixel_shuffle: int = 1,
     out_scale: float = 1.0,
@@ -127,14 +125,6 @@ def conv_params(
         p.out_plane_off = out_plane_off
         p.out_plane_stride = out.plane_stride
         p.out_batch_stride = out.batch_stride
-    if pre is not None:
-        if (pre.h, pre.w, pre.n) != (H, W, x.n) or pre_plane_off + nplanes_out > pre.planes:
-            raise ValueError('pre-activation planes do not match the convolution output')
-        p.pre_hi = pre.hi_ptr()
-        p.pre_lo = pre.lo_ptr()
-        p.pre_plane_off = pre_plane_off
-        p.pre_plane_stride = pre.plane_stride
-        p.pre_batch_stride = pre.batch_stride
     p.pixel_shuffle = pixel_shuffle
     p.out_scale = out_scale
     if out_nchw is not None:

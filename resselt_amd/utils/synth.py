@@ -1,0 +1,131 @@
+"""Deterministic synthetic checkpoints (there is no network: no real weights can be downloaded).
+
+Every tensor is drawn from uniform(-1/sqrt(fan_in), +1/sqrt(fan_in)) -- PyTorch's default conv/linear
+init scale -- by a numpy PCG64 stream keyed by the tensor's *name*, so the same state dict can be rebuilt
+bit-for-bit on the GPU box without the reference, and the golden fixtures in ``tests/golden`` only need to
+store seeds, inputs and expected outputs.
+"""
+
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+
+def synth_tensor(name: str, shape, fan_in: int, seed: int = 0, scale: float = 1.0) -> torch.Tensor:
+    rng = np.random.Generator(np.random.PCG64([zlib.crc32(name.encode()), seed]))
+    bound = scale / float(np.sqrt(max(fan_in, 1)))
+    a = rng.uniform(-bound, bound, size=tuple(shape)).astype(np.float32)
+    return torch.from_numpy(a)
+
+
+def synth_input(shape, seed: int = 0) -> torch.Tensor:
+    """Image-like input in [0, 1), fp32."""
+    rng = np.random.Generator(np.random.PCG64([0x1A6E, seed]))
+    return torch.from_numpy(rng.random(size=tuple(shape), dtype=np.float32))
+
+
+def _conv(sd, name, cout, cin, k, seed, bias=True, scale=1.0):
+    fan_in = cin * k * k
+    sd[f'{name}.weight'] = synth_tensor(f'{name}.weight', (cout, cin, k, k), fan_in, seed, scale)
+    if bias:
+        sd[f'{name}.bias'] = synth_tensor(f'{name}.bias', (cout,), fan_in, seed, scale)
+
+
+def rrdbnet_state_dict(in_nc=3, out_nc=3, nf=64, nb=23, gc=32, scale=4, plus=False, seed=0, new_arch=False) -> 'OrderedDict[str, torch.Tensor]':
+    """Old-arch (ESRGAN) keys; ``new_arch=True`` renames them to the official Real-ESRGAN spelling."""
+    sd: OrderedDict = OrderedDict()
+    _conv(sd, 'model.0', nf, in_nc, 3, seed)
+    for i in range(nb):
+        for r in (1, 2, 3):
+            p = f'model.1.sub.{i}.RDB{r}'
+            if plus:
+                _conv(sd, f'{p}.conv1x1', gc, nf, 1, seed, bias=False)
+            for j in range(1, 6):
+                _conv(sd, f'{p}.conv{j}.0', gc if j < 5 else nf, nf + (j - 1) * gc, 3, seed)
+    _conv(sd, f'model.1.sub.{nb}', nf, nf, 3, seed)
+    k = 3
+    n_up = {1: 0, 2: 1, 4: 2, 8: 3}[scale]
+    for _ in range(n_up):
+        _conv(sd, f'model.{k}', nf, nf, 3, seed)
+        k += 3
+    k -= 1
+    _conv(sd, f'model.{k}', nf, nf, 3, seed)
+    _conv(sd, f'model.{k + 2}', out_nc, nf, 3, seed)
+    if not new_arch:
+        return sd
+    out: OrderedDict = OrderedDict()
+    for key, v in sd.items():
+        parts = key.split('.')
+        kind = parts[-1]
+        if key.startswith('model.0.'):
+            out[f'conv_first.{kind}'] = v
+        elif key.startswith('model.1.sub.') and len(parts) == 5:
+            out[f'conv_body.{kind}'] = v
+        elif key.startswith('model.1.sub.'):
+            out[f'body.{parts[3]}.rdb{parts[4][3:]}.{parts[5]}.{kind}'] = v
+        else:
+            idx = int(parts[1])
+            if idx == k:
+                out[f'conv_hr.{kind}'] = v
+            elif idx == k + 2:
+                out[f'conv_last.{kind}'] = v
+            else:
+                out[f'conv_up{idx // 3}.{kind}'] = v
+    return out
+
+
+def _conv3xc(sd, name, cout, cin, gain, seed):
+    _conv(sd, f'{name}.sk', cout, cin, 1, seed)
+    _conv(sd, f'{name}.conv.0', cin * gain, cin, 1, seed)
+    _conv(sd, f'{name}.conv.1', cout * gain, cin * gain, 3, seed)
+    _conv(sd, f'{name}.conv.2', cout, cout * gain, 1, seed)
+    # stored eval_conv is overwritten by the fold on every reference forward; keep a placeholder of the right shape
+    _conv(sd, f'{name}.eval_conv', cout, cin, 3, seed)
+
+
+def _spab(sd, name, c, seed):
+    for r in ('c1_r', 'c2_r', 'c3_r'):
+        _conv3xc(sd, f'{name}.{r}', c, c, 2, seed)
+
+
+def spanplus_state_dict(num_in_ch=3, num_out_ch=3, blocks=(4,), feature_channels=48, upscale=4, upsampler='ps', seed=0):
+    sd: OrderedDict = OrderedDict()
+    fc = feature_channels
+    _conv3xc(sd, 'feats.0', fc, num_in_ch, 2, seed)
+    for bi, nblk in enumerate(blocks):
+        p = f'feats.{bi + 1}'
+        _spab(sd, f'{p}.block_1', fc, seed)
+        for j in range(nblk):
+            _spab(sd, f'{p}.block_n.{j}', fc, seed)
+        _spab(sd, f'{p}.block_end', fc, seed)
+        _conv3xc(sd, f'{p}.conv_2', fc, fc, 2, seed)
+        _conv(sd, f'{p}.conv_cat', fc, fc * 4, 1, seed)
+    if upsampler == 'ps':
+        _conv(sd, 'upsampler.0', num_in_ch * upscale * upscale, fc, 3, seed)
+    else:
+        groups = 4
+        oc = 2 * groups * upscale * upscale
+        _conv(sd, 'upsampler.end_conv', num_out_ch, fc, 1, seed)
+        _conv(sd, 'upsampler.offset', oc, fc, 1, seed)
+        _conv(sd, 'upsampler.scope', oc, fc, 1, seed, bias=False)
+        h = torch.arange((-upscale + 1) / 2, (upscale - 1) / 2 + 1) / upscale
+        sd['upsampler.init_pos'] = torch.stack(torch.meshgrid([h, h], indexing='ij')).transpose(1, 2).repeat(1, groups, 1).reshape(1, -1, 1, 1)
+    return sd
+
+
+def span_state_dict(num_in_ch=3, feature_channels=48, upscale=4, seed=0, norm=True):
+    sd: OrderedDict = OrderedDict()
+    fc = feature_channels
+    _conv3xc(sd, 'conv_1', fc, num_in_ch, 2, seed)
+    for i in range(1, 7):
+        _spab(sd, f'block_{i}', fc, seed)
+    _conv(sd, 'conv_cat', fc, fc * 4, 1, seed)
+    _conv3xc(sd, 'conv_2', fc, fc, 2, seed)
+    _conv(sd, 'upsampler.0', num_in_ch * upscale * upscale, fc, 3, seed)
+    if not norm:
+        sd['no_norm'] = torch.zeros(1)
+    return sd

@@ -124,7 +124,7 @@ def test_conv_upsample_lrelu(device, products):
 
 
 @pytest.mark.parametrize('act,fn', [(L.ACT_MISH, F.mish), (L.ACT_SILU, F.silu), (L.ACT_GELU, F.gelu)])
-def test_conv_activations_and_pre(device, act, fn):
+def test_conv_activations(device, act, fn):
     n, h, w = 1, 13, 18
     x = _rand((n, 48, h, w), 21, 2.0)
     wt = _rand((48, 48, 3, 3), 22, 3.0 / (48 * 9) ** 0.5)
@@ -133,14 +133,11 @@ def test_conv_activations_and_pre(device, act, fn):
     ref = fn(pre_ref)
     wts = ops.ConvWeights.from_oihw(wt, b, 3, device=device)
     xin = tensors.nchw_to_planes(x.to(device))
-    pre = tensors.Planes.empty(n, 6, h, w, device)
     onchw = torch.empty((n, 48, h, w), dtype=torch.float32, device=device)
-    p = ops.conv_params(wts, xin, h, w, act=act, pre=pre, out_nchw=onchw)
+    p = ops.conv_params(wts, xin, h, w, act=act, out_nchw=onchw)
     ops.run_convs([p], device)
     torch.cuda.synchronize()
     _check(onchw, ref, 3, 'activation')
-    got = tensors.planes_to_nchw(pre, 48)
-    assert (got.cpu() - pre_ref).abs().max().item() <= 3e-5 * pre_ref.abs().max().item()
 
 
 def test_conv_spab_gate_and_pixelshuffle(device):

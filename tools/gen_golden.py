@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by running the REAL reference (rewaifu/resselt).
+
+Runs only in the build container, where /root/reference is mounted read-only.  Nothing of the reference is
+copied: it is imported, fed deterministic synthetic checkpoints (resselt_amd/utils/synth.py) and seeded
+inputs, and only the resulting input/output *vectors* (+ the metadata the reference's loaders inferred)
+are written, as compressed .npz files.
+
+Shims applied before import (both are harness-side, the reference tree is untouched):
+  1. ``typing.Self`` (Python 3.10 lacks it; archs/smosr/arch.py:1 and archs/spanpp/arch.py:2 import it);
+  2. DySample asks for ``pin_memory=True`` (utilities/dysample.py:62), which raises on a GPU-less host: the
+     ``torch`` name inside that module is replaced by a proxy whose ``tensor()`` drops the flag.
+
+Usage:  python tools/gen_golden.py            # rewrites tests/golden/*.npz
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+import typing
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+import typing_extensions  # noqa: E402
+
+if not hasattr(typing, 'Self'):
+    typing.Self = typing_extensions.Self  # shim 1
+sys.path.insert(0, '/root/reference')
+
+import torch  # noqa: E402
+
+import resselt  # noqa: E402  (the reference)
+import resselt.utilities.dysample as _ref_dys  # noqa: E402
+from resselt.utilities import block as RB  # noqa: E402
+
+from resselt_amd.utils import synth  # noqa: E402
+
+
+class _TorchNoPin:  # shim 2
+    def __getattr__(self, name):
+        return getattr(torch, name)
+
+    @staticmethod
+    def tensor(*args, **kwargs):
+        kwargs.pop('pin_memory', None)
+        return torch.tensor(*args, **kwargs)
+
+
+_ref_dys.torch = _TorchNoPin()
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+
+def save(name: str, meta: dict, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    meta = dict(meta, torch=torch.__version__, generator='tools/gen_golden.py')
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), meta=np.array(json.dumps(meta)), **{k: np.asarray(v) for k, v in arrays.items()})
+    sizes = {k: tuple(np.asarray(v).shape) for k, v in arrays.items()}
+    print(f'{name}: {sizes}')
+
+
+def meta_of(model) -> dict:
+    pi = model.parameters_info
+    return dict(in_channels=pi.in_channels, out_channels=pi.out_channels, upscale=pi.upscale, name=pi.name, cls=type(model).__name__)
+
+
+# ------------------------------------------------------------------ RRDBNet / ESRGAN
+def esrgan_cases():
+    cases = [
+        ('rrdbnet_x4_nb23_32x32', dict(nb=23, scale=4), (1, 3, 32, 32), 1),
+        ('rrdbnet_x4_nb23_40x56', dict(nb=23, scale=4), (1, 3, 40, 56), 2),
+        ('rrdbnet_x2_nb3_b2_19x27', dict(nb=3, scale=2), (2, 3, 19, 27), 3),
+        ('rrdbnet_x1_nb2_17x33', dict(nb=2, scale=1), (1, 3, 17, 33), 4),
+        ('rrdbnet_plus_x4_nb2_24x24', dict(nb=2, scale=4, plus=True), (1, 3, 24, 24), 5),
+        ('rrdbnet_x2plus_unshuffle_nb2_21x30', dict(nb=2, scale=4, in_nc=12), (1, 3, 21, 30), 6),
+        ('rrdbnet_x4_nf32_nb1_1x1', dict(nb=1, scale=4, nf=32), (1, 3, 1, 1), 7),
+    ]
+    for name, kw, shape, seed in cases:
+        sd = synth.rrdbnet_state_dict(seed=seed, **kw)
+        model = resselt.load_from_state_dict(dict(sd))
+        x = synth.synth_input(shape, seed)
+        y = model(x)
+        save(name, dict(arch='esrgan', synth=kw, seed=seed, metadata=meta_of(model)), x=x, y=y)
+
+    # loader-only fixtures: what the reference's ESRGANArch.load infers for the other key spellings.
+    # (registry.load_from_state_dict fails for new-arch keys in the reference -- SURVEY.md §3.1 -- so arch.load is called directly.)
+    arch = resselt.get('ESRGAN')
+    infos = {}
+    for tag, kw in (
+        ('old', dict(nb=3, scale=4)),
+        ('new', dict(nb=3, scale=4, new_arch=True)),
+        ('new_x2', dict(nb=2, scale=2, new_arch=True)),
+        ('plus', dict(nb=2, scale=4, plus=True)),
+        ('x2plus', dict(nb=2, scale=4, in_nc=12)),
+        ('x1_unshuffle4', dict(nb=2, scale=4, in_nc=48)),
+    ):
+        sd = synth.rrdbnet_state_dict(seed=0, **kw)
+        assert arch.detect(sd)
+        m = arch.load(dict(sd))
+        infos[tag] = dict(synth=kw, metadata=meta_of(m), n_params=len(m.state_dict()), shuffle_factor=m.shuffle_factor, model_scale=m.scale)
+    save('esrgan_loader', dict(arch='esrgan', cases=infos))
+
+
+def block_cases():
+    """Per-block vectors from the reference's shared blocks (utilities/block.py)."""
+    seed = 11
+    sd_full = synth.rrdbnet_state_dict(nb=1, seed=seed)
+    x = synth.synth_input((1, 64, 12, 20), seed) * 2 - 1
+    rdb = RB.ResidualDenseBlock_5C(64, 3, 32, 1, True, 'zero', None, 'leakyrelu', 'CNA')
+    rdb.load_state_dict({k[len('model.1.sub.0.RDB1.') :]: v for k, v in sd_full.items() if k.startswith('model.1.sub.0.RDB1.')})
+    rrdb = RB.RRDB(64, 3, 32, 1, True, 'zero', None, 'leakyrelu', 'CNA')
+    rrdb.load_state_dict({k[len('model.1.sub.0.') :]: v for k, v in sd_full.items() if k.startswith('model.1.sub.0.')})
+    up = RB.upconv_block(64, 64, act_type='leakyrelu')
+    up.load_state_dict({'1.weight': sd_full['model.3.weight'], '1.bias': sd_full['model.3.bias']})
+    save('blocks_rrdb', dict(arch='esrgan', seed=seed, synth=dict(nb=1)), x=x, rdb=rdb(x), rrdb=rrdb(x), upconv=up(x))
+
+
+# ------------------------------------------------------------------ SPAN / SPANPlus
+def span_cases():
+    from resselt.archs.spanplus.arch import SPAB as RefSPAB
+    from resselt.archs.spanplus.arch import Conv3XC as RefConv3XC
+
+    cases = [
+        ('spanplus_ps_x2_24x40', dict(upscale=2, upsampler='ps'), (1, 3, 24, 40), 21),
+        ('spanplus_ps_x4_b2_17x23', dict(upscale=4, upsampler='ps'), (2, 3, 17, 23), 22),
+        ('spanplus_dys_x2_24x40', dict(upscale=2, upsampler='dys'), (1, 3, 24, 40), 23),
+        ('spanplus_dys_x4_20x28', dict(upscale=4, upsampler='dys'), (1, 3, 20, 28), 24),
+        ('spanplus_ps_x4_blocks2_2_fc32', dict(upscale=4, upsampler='ps', blocks=(2, 2), feature_channels=32), (1, 3, 16, 16), 25),
+    ]
+    for name, kw, shape, seed in cases:
+        sd = synth.spanplus_state_dict(seed=seed, **kw)
+        model = resselt.load_from_state_dict(dict(sd))
+        x = synth.synth_input(shape, seed)
+        y_train = model(x)  # the loader returns the module in training mode (unfused Conv3XC path)
+        y_eval = model.eval()(x)  # folded path
+        kw = dict(kw, blocks=list(kw.get('blocks', (4,))))
+        save(name, dict(arch='spanplus', synth=kw, seed=seed, metadata=meta_of(model), train_eval_maxdiff=float((y_train - y_eval).abs().max())), x=x, y=y_train)
+
+    for name, kw, shape, seed in [
+        ('span_x4_24x40', dict(upscale=4), (1, 3, 24, 40), 31),
+        ('span_x2_nonorm_19x21', dict(upscale=2, norm=False), (1, 3, 19, 21), 32),
+    ]:
+        sd = synth.span_state_dict(seed=seed, **kw)
+        model = resselt.load_from_state_dict(dict(sd))
+        x = synth.synth_input(shape, seed)
+        save(name, dict(arch='span', synth=kw, seed=seed, metadata=meta_of(model)), x=x, y=model(x))
+
+    # Conv3XC fold and one SPAB, straight from the reference classes
+    seed = 41
+    sd = synth.spanplus_state_dict(seed=seed)
+    c = RefConv3XC(48, 48, gain=2, s=1)
+    c.load_state_dict({k[len('feats.1.block_1.c1_r.') :]: v for k, v in sd.items() if k.startswith('feats.1.block_1.c1_r.')})
+    c.update_params()
+    blk = RefSPAB(48, end=True)
+    blk.load_state_dict({k[len('feats.1.block_1.') :]: v for k, v in sd.items() if k.startswith('feats.1.block_1.')})
+    x = synth.synth_input((1, 48, 10, 14), seed) * 2 - 1
+    out, out1 = blk(x)
+    save('blocks_span', dict(arch='spanplus', seed=seed, synth={}), x=x, fold_w=c.eval_conv.weight.data, fold_b=c.eval_conv.bias.data, spab_out=out, spab_out1=out1)
+
+
+def registry_cases():
+    """Detection order facts: which reference architecture claims each synthetic checkpoint."""
+    claims = {}
+    for tag, sd in (
+        ('rrdbnet_old', synth.rrdbnet_state_dict(nb=1)),
+        ('spanplus_ps', synth.spanplus_state_dict(upsampler='ps')),
+        ('spanplus_dys', synth.spanplus_state_dict(upsampler='dys')),
+        ('span', synth.span_state_dict()),
+    ):
+        for arch in resselt.archs.internal_registry.store.values():
+            if arch.detect(sd):
+                claims[tag] = arch.id
+                break
+    save('registry_claims', dict(claims=claims, order=list(resselt.archs.internal_registry.store.keys())))
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['esrgan', 'blocks', 'span', 'registry', 'swinir']
+    if 'esrgan' in which:
+        esrgan_cases()
+    if 'blocks' in which:
+        block_cases()
+    if 'span' in which:
+        span_cases()
+    if 'registry' in which:
+        registry_cases()
+    if 'swinir' in which:
+        try:
+            from gen_golden_swinir import swinir_cases  # type: ignore
+        except ImportError:
+            swinir_cases = None
+        if swinir_cases:
+            swinir_cases(save, meta_of)
