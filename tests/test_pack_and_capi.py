@@ -1,0 +1,98 @@
+"""Host logic around the C-ABI: weight packing layout, library symbols, descriptor validation (no GPU compute)."""
+
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from resselt_amd.engine import lib as L
+from resselt_amd.engine import pack, tensors
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bf16(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize('cout,cin,planes,k,products', [(20, 11, 2, 3, 3), (64, 192, 24, 3, 3), (3, 64, 8, 3, 1), (48, 192, 24, 1, 3), (16, 8, 5, 1, 1)])
+def test_pack_layout_matches_index_formula(cout, cin, planes, k, products):
+    g = torch.Generator().manual_seed(cout * 1000 + cin)
+    w = torch.randn((cout, cin, k, k), generator=g)
+    blob = pack.pack_conv_weights(w, planes, products)
+    assert tuple(blob.shape) == pack.packed_weight_shape(cout, planes, k, products) and blob.dtype == torch.bfloat16
+    hi = _bf16(w)
+    lo = _bf16(w - hi.float())
+    q_n, t_n, ct_n, nhl, _, _ = blob.shape
+    rng = torch.Generator().manual_seed(1)
+    for _ in range(400):  # random probes of blob[q][t][ct][hl][lane][j]
+        q, t, ct, hl, lane, j = (int(torch.randint(0, n, (1,), generator=rng)) for n in (q_n, t_n, ct_n, nhl, 64, 8))
+        co, ci = 16 * ct + (lane & 15), 32 * q + 8 * (lane >> 4) + j
+        src = (hi, lo)[hl]
+        want = src[co, ci, t // k, t % k].item() if co < cout and ci < cin else 0.0
+        assert blob[q, t, ct, hl, lane, j].item() == want
+    # hi + lo reproduces the weight to ~2^-17 relative
+    assert ((hi.float() + lo.float()) - w).abs().max() <= 2.0 ** -16 * w.abs().max()
+
+
+def test_packed_bytes_agree_with_library():
+    lib = L.load()
+    for cout, planes, k, prod in [(64, 24, 3, 3), (3, 8, 3, 1), (720, 30, 1, 3), (48, 6, 3, 3)]:
+        shape = pack.packed_weight_shape(cout, planes, k, prod)
+        n = 1
+        for s in shape:
+            n *= s
+        assert lib.rsa_packed_weight_bytes(cout, planes, k, prod) == 2 * n
+    assert lib.rsa_packed_weight_bytes(0, 1, 3, 3) < 0 and lib.rsa_packed_weight_bytes(8, 1, 2, 3) < 0
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'resselt_amd.h')).read()
+    declared = set(re.findall(r'^\s*(?:const\s+)?(?:int|int64_t|char\s*\*|void)\s*\*?\s*(rsa_\w+)\s*\(', header, flags=re.M))
+    assert declared, 'no prototypes parsed from the header'
+    assert declared == set(L.EXPORTS), (declared ^ set(L.EXPORTS))
+    lib = ctypes.CDLL(L.lib_path())
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert L.load().rsa_version() == 100
+
+
+def test_conv_params_struct_matches_header_field_order():
+    header = open(os.path.join(ROOT, 'include', 'resselt_amd.h')).read()
+    body = header[header.index('typedef struct rsa_conv_params {') : header.index('} rsa_conv_params;')]
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    fields = re.findall(r'(?:const\s+)?(?:int32_t|int64_t|float|void\s*\*|float\s*\*)\s*\*?\s*([\w, ]+);', body)
+    names = [n.strip() for grp in fields for n in grp.split(',')]
+    assert names == [f[0] for f in L.ConvParams._fields_]
+
+
+def test_cout_tile_choice():
+    assert [L.cout_tiles(c) for c in (3, 16, 17, 32, 48, 64)] == [1, 1, 2, 2, 3, 4]
+    assert L.cout_tiles(240) == 3 and L.cout_tiles(720) == 3 and L.cout_tiles(480) == 3 and L.cout_tiles(128) == 4
+
+
+def test_argument_validation_without_gpu():
+    lib = L.load()
+    p = L.ConvParams()
+    assert lib.rsa_conv2d(ctypes.byref(p), None) == -1  # RSA_E_ARG: bad geometry
+    assert b'geometry' in lib.rsa_last_error_string()
+    p.batch, p.H, p.W, p.cin_planes, p.cout, p.ksize, p.products = 1, 8, 8, 1, 8, 5, 3
+    assert lib.rsa_conv2d(ctypes.byref(p), None) == -2 and b'ksize' in lib.rsa_last_error_string()
+    p.ksize = 3
+    assert lib.rsa_conv2d(ctypes.byref(p), None) == -1 and b'null' in lib.rsa_last_error_string()
+    p.in_hi, p.in_lo, p.w_packed = 8, 16, 16
+    assert lib.rsa_conv2d(ctypes.byref(p), None) == -3  # misaligned pointer
+    assert lib.rsa_conv2d_list(None, 1, None) == -1
+
+
+def test_layout_reference_conversions_roundtrip():
+    x = torch.randn(2, 13, 5, 7)
+    pl = tensors.nchw_to_planes(x)
+    assert pl.hi.shape == (2, 2, 5, 7, 8) and pl.plane_stride == 35 and pl.batch_stride == 70
+    back = tensors.planes_to_nchw(pl, 13)
+    assert (back - x).abs().max() <= 2.0 ** -16 * x.abs().max()
+    assert tensors.planes_to_nchw(pl, 16)[:, 13:].abs().max() == 0
+    m = tensors.nchw_to_f32map(x)
+    assert m.shape == (2, 4, 5, 7, 4) and torch.equal(tensors.f32map_to_nchw(m, 13), x)
