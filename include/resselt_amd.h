@@ -105,7 +105,8 @@ typedef struct rsa_conv_params {
   int64_t out_batch_stride; /* units */
   float* out_f32;           /* f32 NCHW4c residual stream */
 
-  void* out_nchw;           /* final plain tensor [N][cout/r^2][H*r][W*r], dtype out_dtype */
+  void* out_nchw;           /* final plain tensor [N][cout/r^2][H*r][W*r], dtype out_dtype; exclusive with
+                               out_hi/out_f32/res1/res2 (separate kernel instantiation) */
   int32_t out_dtype;        /* enum rsa_dtype */
   int32_t pixel_shuffle;    /* r >= 1 (depth-to-space factor applied while storing out_nchw) */
   float out_scale;          /* out_nchw value = v * out_scale + out_shift[oc]  (SwinIR x/img_range + mean, */
@@ -142,6 +143,29 @@ int rsa_nchw_to_planes(const void* x, int32_t dtype, int32_t batch, int32_t C, i
 /* split planes / f32 NCHW4c -> plain NCHW (debug + parity of intermediates) */
 int rsa_planes_to_nchw(const void* hi, const void* lo, int64_t plane_stride, int64_t batch_stride, int32_t batch,
                        int32_t C, int32_t H, int32_t W, float* out, void* stream);
+
+/*
+ * DySample upsampler head: sigmoid-gated learned offsets -> bilinear border gather over channel groups -> 1x1 conv.
+ * Replaces resselt/utilities/dysample.py:47-83 after the two 1x1 offset/scope convs (run as ONE rsa_conv2d whose
+ * f32 NCHW4c output holds offset channels [0, oc) and scope channels [oc, 2*oc), oc = 2*groups*scale^2).
+ */
+typedef struct rsa_dysample_params {
+  int32_t batch;
+  int32_t H, W;          /* low-resolution size */
+  int32_t C;             /* feature channels, multiple of 4*groups */
+  int32_t groups;        /* 4 in the reference */
+  int32_t scale;
+  int32_t out_ch;        /* 1..8 */
+  const float* x_f32;    /* features, f32 NCHW4c [N][C/4][H][W][4] */
+  const float* offscope; /* f32 NCHW4c [N][2*oc/4][H][W][4] */
+  const float* init_pos; /* [oc] (registered buffer of the reference module, dysample.py:43-45) */
+  const float* end_w;    /* [out_ch][C] */
+  const float* end_b;    /* [out_ch] or NULL */
+  void* out_nchw;        /* [N][out_ch][H*scale][W*scale] */
+  int32_t out_dtype;     /* enum rsa_dtype */
+} rsa_dysample_params;
+
+int rsa_dysample(const rsa_dysample_params* p, void* stream);
 
 /* version / errors */
 int rsa_version(void);

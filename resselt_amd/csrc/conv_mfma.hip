@@ -4,20 +4,24 @@
 // residual(s) -> [PixelShuffle] (utilities/block.py:148-200,340-344,454-465,510-537 of the
 // reference); see include/resselt_amd.h for the contract and DESIGN.md §3 for the layout.
 //
-// Mapping (one workgroup = 256 threads = 4 waves, two workgroups per CU):
-//   output tile   : TH x TW = 8 x 32 pixels, NCT cout-tiles of 16 channels
-//   wave w        : rows 2w, 2w+1 of the tile = 4 pixel-tiles of 16 consecutive pixels
+// Mapping (one workgroup = 256 threads = 4 waves, two workgroups per CU, persistent over tiles):
+//   output tile   : 32 pixels wide; 8 rows (cout slab of 3-4 tiles of 16) or 16 rows (1-2 tiles)
+//   wave          : 8 pixel-tiles (4 rows x 2 x 16 pixels) x 2 cout-tiles of 16 channels = 16 accumulator tiles
 //   MFMA          : v_mfma_f32_16x16x32_bf16,  D[cout 16][pixel 16] += A[cout][k 32] * B[k][pixel]
-//                   A = weights (lane l: cout l&15, k-group l>>4), pre-packed in fragment order
+//                   A = weights (lane l: cout l&15, k-group l>>4), pre-packed in fragment order and streamed by each
+//                       wave straight from L2 into VGPRs one tap ahead (waves own disjoint cout tiles or rows, so
+//                       nothing is shared through LDS and no barrier guards the weights)
 //                   B = activations: lane l reads ONE 16-byte unit = 8 channels of pixel (l&15) in
 //                       plane (4q + (l>>4)) of the LDS halo tile, shifted by the tap (dy,dx)
 //   K loop        : chunks q of 4 planes (32 channels) x taps t; the halo tile of a chunk is staged
-//                   once in LDS and reused by all 9 taps; weights of a tap go through a 2-deep LDS ring
+//                   once in LDS (two barriers per chunk) and reused by all 9 taps
 //   LDS halo tile : [hi|lo][plane 0..3][IH][IW] units, plane stride PS = 0 (mod 16 units) so that every
 //                   ds_read_b128 lane group (8 lanes of plane p + 8 lanes of plane p+1, pixel offsets
-//                   covering 0..15 once) hits 16 distinct 16-byte slots for ANY tap offset
-//   global->LDS   : register-staged (issue-early / write-late): chunk q+1 is fetched into VGPRs while
-//                   the 9 taps of chunk q run on the matrix cores
+//                   covering 0..15 once) hits 16 distinct 16-byte slots for ANY tap offset (measured:
+//                   SQ_LDS_BANK_CONFLICT = 0)
+//   global->LDS   : register-staged (issue-early / write-late) raw buffer loads: item (tile, q)+1 is fetched into
+//                   VGPRs while the 9 taps of item (tile, q) run on the matrix cores; zero padding and missing
+//                   planes come from the buffer range check (no branches, loads stay in flight)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -29,9 +33,8 @@ namespace rsa {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-constexpr int TH = 8;
-constexpr int TW = 32;
 constexpr int NPL = 4;  // planes per K chunk (32 channels = one MFMA K)
 constexpr int NTHREADS = 256;
 
@@ -53,61 +56,189 @@ __device__ __forceinline__ float act_apply(float v, int act, float prm) {
   }
 }
 
-__device__ __forceinline__ void split_store(void* hi_base, void* lo_base, int64_t unit, int sub, const float v[4]) {
-  // 4 consecutive channels of one pixel -> 8 bytes in the hi plane, 8 bytes in the lo plane
-  bf16x4 h, l;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+// (a, b) -> packed bf16 pair (RNE) and the pair's rounding residuals, also packed
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const bf16x2 h = {(__bf16)a, (__bf16)b};
+  hi = __builtin_bit_cast(uint32_t, h);
+  const float ra = a - __builtin_bit_cast(float, hi << 16);
+  const float rb = b - __builtin_bit_cast(float, hi & 0xffff0000u);
+  const bf16x2 l = {(__bf16)ra, (__bf16)rb};
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// Geometry of one instantiation.  A workgroup is always 4 waves; a wave always owns 8 pixel-tiles (4 rows x 2 halves
+// of 16 pixels) x CTW cout-tiles, so that one tap costs it 16 LDS fragment reads + 4 weight fragment loads for up to
+// 48 MFMAs.  NCT >= 3: tile 8x32, waves = 2 cout-pairs x 2 row-groups.  NCT <= 2: tile 16x32, waves = 4 row-groups.
+template <int KS, int NCT>
+struct Geo {
+  static constexpr int WCT = (NCT >= 3) ? 2 : 1;       // waves along cout
+  static constexpr int WPX = 4 / WCT;                  // waves along rows
+  static constexpr int CTW = (NCT >= 2) ? 2 : 1;       // cout tiles per wave
+  static constexpr int TH = 4 * WPX;                   // 8 or 16 output rows
+  static constexpr int TW = 32;
+  static constexpr int HALO = KS / 2;
+  static constexpr int IH = TH + 2 * HALO;
+  static constexpr int IW = TW + 2 * HALO;
+  static constexpr int PS = ((IH * IW + 15) / 16) * 16;  // plane stride in units, == 0 mod 16
+};
+
+// Epilogue of one finished tile.  Every address is  (uniform 64-bit base) + (32-bit per-lane byte offset):
+//   lane (li, lg) of wave (wct, wpx) owns, for pixel-tile pt and cout-tile c, the 4 consecutive channels
+//   c0 = 16*(slab*NCT + 2*wct + c) + 4*lg .. +3  of pixel (y0 + 4*wpx + (pt>>1), x0 + 16*(pt&1) + li).
+// OUTK = 0: split planes and/or f32 residual map (with activation / residual epilogues)
+// OUTK = 1: final plain NCHW tensor (optional activation, depth-to-space and affine), any dtype
+template <int NCT, int CTW, int OUTK>
+__device__ __forceinline__ void epilogue(const rsa_conv_params& p, const f32x4 (&acc)[8][CTW], int n, int y0, int x0, int slab, int wct, int wpx,
+                                         int li, int lg) {
+  const int64_t HW = (int64_t)p.H * p.W;
+  const int64_t pix0 = (int64_t)y0 * p.W + x0;  // uniform
+  const int p4 = (p.cout + 3) >> 2;
+  const int cout8 = (p.cout + 7) & ~7;
+  const int ctile0 = slab * NCT + wct * 2;
+
+  uint32_t lpix[8];
+  bool pvalid[8];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    __bf16 hb = (__bf16)v[r];
-    h[r] = hb;
-    l[r] = (__bf16)(v[r] - (float)hb);
+  for (int pt = 0; pt < 8; ++pt) {
+    const int ry = wpx * 4 + (pt >> 1), rx = (pt & 1) * 16 + li;
+    lpix[pt] = (uint32_t)(ry * p.W + rx);
+    pvalid[pt] = (y0 + ry < p.H) && (x0 + rx < p.W);
   }
-  char* ph = (char*)hi_base + unit * 16 + sub * 8;
-  *(bf16x4*)ph = h;
-  if (lo_base) {
-    char* pl = (char*)lo_base + unit * 16 + sub * 8;
-    *(bf16x4*)pl = l;
+
+#pragma unroll
+  for (int ct = 0; ct < CTW; ++ct) {
+    if (wct * 2 + ct >= NCT) break;
+    const int cbase = (ctile0 + ct) * 16;  // uniform
+    if (cbase >= cout8) break;
+    const int c0 = cbase + lg * 4;
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr) bias = ((const f32x4*)p.bias)[c0 >> 2];  // bias is padded to a multiple of 16
+    const bool cvalid = c0 < cout8;
+    const bool has_f32grp = c0 < (p4 << 2);
+    // uniform bases for this cout tile
+    const char* r1b = (const char*)p.res1 + (((int64_t)n * p4 + (cbase >> 2)) * HW + pix0) * 16;
+    const char* r2b = (const char*)p.res2 + (((int64_t)n * p4 + (cbase >> 2)) * HW + pix0) * 16;
+    char* f32b = (char*)p.out_f32 + (((int64_t)n * p4 + (cbase >> 2)) * HW + pix0) * 16;
+    const int64_t ounit0 = (int64_t)n * p.out_batch_stride + (int64_t)(p.out_plane_off + (cbase >> 3)) * p.out_plane_stride + pix0;
+    char* ohb = (char*)p.out_hi + ounit0 * 16;
+    char* olb = (char*)p.out_lo + ounit0 * 16;
+    const uint32_t f32lane = (uint32_t)lg * (uint32_t)HW;                       // + lpix, in float4 units
+    const uint32_t pllane = (uint32_t)(lg >> 1) * (uint32_t)p.out_plane_stride;  // + lpix, in 16-byte units
+#pragma unroll
+    for (int pt = 0; pt < 8; ++pt) {
+      if (!pvalid[pt] || !cvalid) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[pt][ct][r] + bias[r];
+      if (OUTK == 0) {
+        const uint32_t foff = (f32lane + lpix[pt]) * 16u;
+        if (p.act == RSA_ACT_SPAB_GATE) {
+          f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+          if (has_f32grp) rr = *(const f32x4*)(r1b + foff);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sg = 1.f / (1.f + expf(-v[r]));
+            v[r] = (v[r] + rr[r]) * (sg - 0.5f);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act, p.act_param);
+          if (p.res1 != nullptr && has_f32grp) {
+            const f32x4 rr = *(const f32x4*)(r1b + foff);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + rr[r];
+          }
+        }
+        if (p.res2 != nullptr && has_f32grp) {
+          const f32x4 rr = *(const f32x4*)(r2b + foff);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] * p.beta + rr[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (c0 + r >= p.cout) v[r] = 0.f;
+        if (p.out_hi != nullptr) {
+          uint32_t h0, l0, h1, l1;
+          split2(v[0], v[1], h0, l0);
+          split2(v[2], v[3], h1, l1);
+          const uint32_t uoff = (pllane + lpix[pt]) * 16u + (uint32_t)(lg & 1) * 8u;
+          *(uint2*)(ohb + uoff) = make_uint2(h0, h1);
+          if (p.out_lo != nullptr) *(uint2*)(olb + uoff) = make_uint2(l0, l1);
+        }
+        if (p.out_f32 != nullptr && has_f32grp) *(f32x4*)(f32b + foff) = (f32x4){v[0], v[1], v[2], v[3]};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act, p.act_param);
+        const int ps = p.pixel_shuffle > 1 ? p.pixel_shuffle : 1;
+        const int oc_total = p.cout / (ps * ps);
+        const int64_t oW = (int64_t)p.W * ps;
+        const int64_t oHW = (int64_t)p.H * ps * oW;
+        const int y = y0 + wpx * 4 + (pt >> 1), x = x0 + (pt & 1) * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = c0 + r;
+          if (c >= p.cout) continue;
+          const int oc = c / (ps * ps);
+          const int rem = c - oc * ps * ps;
+          const int ii = rem / ps;
+          const int jj = rem - ii * ps;
+          float o = v[r] * p.out_scale;
+          if (p.out_shift != nullptr) o += p.out_shift[oc];
+          const int64_t idx = ((int64_t)n * oc_total + oc) * oHW + ((int64_t)y * ps + ii) * oW + ((int64_t)x * ps + jj);
+          if (p.out_dtype == RSA_F32)
+            ((float*)p.out_nchw)[idx] = o;
+          else if (p.out_dtype == RSA_F16)
+            ((_Float16*)p.out_nchw)[idx] = (_Float16)o;
+          else
+            ((__bf16*)p.out_nchw)[idx] = (__bf16)o;
+        }
+      }
+    }
   }
 }
 
-template <int KS, int NCT, int PROD, int UP>
+template <int KS, int NCT, int PROD, int UP, int OUTK>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_kernel(const rsa_conv_params p) {
-  constexpr int HALO = KS / 2;
-  constexpr int IH = TH + 2 * HALO;
-  constexpr int IW = TW + 2 * HALO;
-  constexpr int PS = ((IH * IW + 15) / 16) * 16;  // plane stride in units, == 0 mod 16
+  using G = Geo<KS, NCT>;
+  constexpr int TH = G::TH, TW = G::TW, HALO = G::HALO, IH = G::IH, IW = G::IW, PS = G::PS;
+  constexpr int WPX = G::WPX, CTW = G::CTW;
   constexpr int ACT_UNITS = NPL * PS;
   constexpr int NHL = (PROD == 3) ? 2 : 1;
   constexpr int FILL_IT = (ACT_UNITS + NTHREADS - 1) / NTHREADS;
-  constexpr int W_UNITS = NCT * NHL * 64;
-  constexpr int W_IT = (W_UNITS + NTHREADS - 1) / NTHREADS;
   constexpr int T = KS * KS;
 
   __shared__ uint4 s_act[NHL * ACT_UNITS];
-  __shared__ uint4 s_w[2 * W_UNITS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wct = wave / WPX;  // which cout pair
+  const int wpx = wave - wct * WPX;  // which group of 4 rows
   const int li = lane & 15;
   const int lg = lane >> 4;
 
   const int tiles_x = (p.W + TW - 1) / TW;
-  const int tile = blockIdx.x;
-  const int ty = tile / tiles_x;
-  const int tx = tile - ty * tiles_x;
-  const int y0 = ty * TH;
-  const int x0 = tx * TW;
+  const int tiles_y = (p.H + TH - 1) / TH;
+  const int tiles_img = tiles_x * tiles_y;
+  const int num_tiles = tiles_img * p.batch;
   const int slab = blockIdx.y;
-  const int n = blockIdx.z;
 
-  const int inH = UP ? (p.H >> 1) : p.H;
   const int inW = UP ? (p.W >> 1) : p.W;
-  (void)inH;
 
-  // ---- per-thread halo-fill map (identical for every chunk) ----
+  const int nchunks = (p.cin_planes + NPL - 1) / NPL;
+  const int nsteps = nchunks * T;
+  const int ct_total = (p.cout + 15) >> 4;
+
+  // ---- per-thread halo-fill map of the tile being FETCHED (recomputed when the prefetch moves to a new tile).
+  //      foff = BYTE offset from the chunk's first plane, or 0xFFFFFFFF for zero padding: the fetch is a raw buffer
+  //      load whose descriptor covers exactly the chunk's valid planes, so padding pixels AND missing planes come
+  //      back as zeros from the hardware range check -- no branch, no select, loads stay in flight (counted vmcnt). ----
   uint32_t foff[FILL_IT];
-  uint32_t fmeta = 0;  // per iteration: bit (4*it+2) = in-image, bits (4*it..4*it+1) = plane in chunk
+  // tile-independent part of the map, packed so that it costs ONE register per fill iteration:
+  //   bits 0-1 plane in chunk, bits 2-7 row in halo tile, bits 8-13 column, bit 16 = slot is part of the halo tile
+  uint32_t fpk[FILL_IT];
 #pragma unroll
   for (int it = 0; it < FILL_IT; ++it) {
     const int u = it * NTHREADS + tid;
@@ -115,45 +246,55 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_kernel(const rsa_conv_params
     const int r = u - pl * PS;
     const int py = r / IW;
     const int px = r - py * IW;
-    int iy = y0 - HALO + py;
-    int ix = x0 - HALO + px;
-    const bool ok = (u < ACT_UNITS) && (r < IH * IW) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-    if (UP) {
-      iy >>= 1;
-      ix >>= 1;
-    }
-    foff[it] = ok ? (uint32_t)(pl * (uint32_t)p.in_plane_stride + (uint32_t)iy * (uint32_t)inW + (uint32_t)ix) : 0u;
-    fmeta |= ((uint32_t)(pl & 3) | (ok ? 4u : 0u)) << (4 * it);
+    fpk[it] = (uint32_t)pl | ((uint32_t)py << 2) | ((uint32_t)px << 8) | ((u < ACT_UNITS && r < IH * IW) ? 0x10000u : 0u);
+    asm volatile("" : "+v"(fpk[it]));  // keep it packed: do not let the compiler hoist the unpacked fields as loop invariants
   }
-
-  const int nchunks = (p.cin_planes + NPL - 1) / NPL;
-  const int nsteps = nchunks * T;
-  const int ct_total = (p.cout + 15) >> 4;
-
-  const uint4* g_hi = (const uint4*)p.in_hi + (int64_t)n * p.in_batch_stride;
-  const uint4* g_lo = (PROD == 3) ? ((const uint4*)p.in_lo + (int64_t)n * p.in_batch_stride) : nullptr;
-  const uint4* g_w = (const uint4*)p.w_packed;
+  const char* f_hi = nullptr;  // image base of the tile being fetched
+  const char* f_lo = nullptr;
+  const uint32_t plane_bytes = (uint32_t)p.in_plane_stride * 16u;
+  auto set_fill_tile = [&](int tile) {
+    const int n = tile / tiles_img;
+    const int tr = tile - n * tiles_img;
+    const int ty = tr / tiles_x;
+    const int tx = tr - ty * tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+    f_hi = (const char*)p.in_hi + (int64_t)n * p.in_batch_stride * 16;
+    if (PROD == 3) f_lo = (const char*)p.in_lo + (int64_t)n * p.in_batch_stride * 16;
+#pragma unroll
+    for (int it = 0; it < FILL_IT; ++it) {
+      const uint32_t k = fpk[it];
+      int iy = y0 - HALO + (int)((k >> 2) & 63u);
+      int ix = x0 - HALO + (int)((k >> 8) & 63u);
+      const bool ok = (k & 0x10000u) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      if (UP) {
+        iy >>= 1;
+        ix >>= 1;
+      }
+      foff[it] = ok ? ((k & 3u) * plane_bytes + ((uint32_t)iy * (uint32_t)inW + (uint32_t)ix) * 16u) : 0xFFFFFFFFu;
+    }
+  };
 
   uint4 st_hi[FILL_IT];
   uint4 st_lo[(PROD == 3) ? FILL_IT : 1];
-  uint4 st_w[W_IT];
 
-  auto load_act = [&](int q) {
-    const int planes_left = p.cin_planes - q * NPL;  // >= 1
-    const uint4* bh = g_hi + (int64_t)q * NPL * p.in_plane_stride;
-    const uint4* bl = (PROD == 3) ? (g_lo + (int64_t)q * NPL * p.in_plane_stride) : nullptr;
+  // `enable == false` issues the same loads against an empty descriptor (all zeros, no memory traffic): the fetch stays
+  // straight-line code, so the compiler can keep it in flight behind a COUNTED vmcnt instead of draining at a join
+  auto load_act = [&](int q, bool enable) {
+    const int planes_left = min(p.cin_planes - q * NPL, NPL);  // >= 1
+    const uint32_t nbytes = enable ? (uint32_t)planes_left * plane_bytes : 0u;
+    const int64_t chunk_off = (int64_t)q * NPL * p.in_plane_stride * 16;
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)(f_hi + chunk_off), 0, nbytes, 0x00020000);
 #pragma unroll
     for (int it = 0; it < FILL_IT; ++it) {
-      const uint32_t m = fmeta >> (4 * it);
-      const bool ok = (m & 4u) && ((int)(m & 3u) < planes_left);
-      const uint32_t off = ok ? foff[it] : 0u;
-      uint4 vh = bh[off];
-      if (!ok) vh = make_uint4(0, 0, 0, 0);
-      st_hi[it] = vh;
-      if (PROD == 3) {
-        uint4 vl = bl[off];
-        if (!ok) vl = make_uint4(0, 0, 0, 0);
-        st_lo[it] = vl;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rh, foff[it], 0, 0);
+      st_hi[it] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+    if (PROD == 3) {
+      const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(f_lo + chunk_off), 0, nbytes, 0x00020000);
+#pragma unroll
+      for (int it = 0; it < FILL_IT; ++it) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rl, foff[it], 0, 0);
+        st_lo[it] = make_uint4(v[0], v[1], v[2], v[3]);
       }
     }
   };
@@ -167,191 +308,171 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_kernel(const rsa_conv_params
       }
     }
   };
-  // weights of step s for this slab: units [(s*ct_total + slab*NCT) * NHL*64, +W_UNITS), tiles past ct_total are zero
+
+  // ---- weights: every wave streams ITS OWN A fragments (cout tiles 2*wct, 2*wct+1 of this slab) straight from the
+  //      L2-resident packed blob into VGPRs, one tap ahead.  No LDS, no barrier: waves never share weight registers. ----
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.w_packed, 0, (uint32_t)((int64_t)nsteps * ct_total * NHL * 64 * 16), 0x00020000);
+  uint32_t woff[CTW];  // byte offset of this lane's fragment of (step 0, cout tile c, hi); 0xFFFFFFFF when the tile does not exist
+#pragma unroll
+  for (int c = 0; c < CTW; ++c) {
+    const int ctg = slab * NCT + wct * 2 + c;
+    woff[c] = (wct * 2 + c < NCT && ctg < ct_total) ? (uint32_t)((ctg * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
+  }
+  const uint32_t wstep = (uint32_t)ct_total * NHL * 64 * 16;  // bytes per step
+  bf16x8 wc[CTW][NHL];  // fragments of the tap being multiplied
+  bf16x8 wn[CTW][NHL];  // fragments of the next tap, in flight
   auto load_w = [&](int s) {
-    const int64_t base = ((int64_t)s * ct_total + (int64_t)slab * NCT) * (NHL * 64);
-    const int valid_units = (ct_total - slab * NCT) * (NHL * 64);  // may exceed W_UNITS
 #pragma unroll
-    for (int it = 0; it < W_IT; ++it) {
-      const int u = it * NTHREADS + tid;
-      const bool ok = (u < W_UNITS) && (u < valid_units);
-      uint4 v = g_w[base + (ok ? u : 0)];
-      if (!ok) v = make_uint4(0, 0, 0, 0);
-      st_w[it] = v;
-    }
-  };
-  auto store_w = [&](int buf) {
+    for (int c = 0; c < CTW; ++c)
 #pragma unroll
-    for (int it = 0; it < W_IT; ++it) {
-      const int u = it * NTHREADS + tid;
-      if (u < W_UNITS) s_w[buf * W_UNITS + u] = st_w[it];
-    }
+      for (int hl = 0; hl < NHL; ++hl) {
+        // a missing cout tile keeps offset 0xFFFFFFFF (s*wstep is far below the wrap) -> zeros from the range check
+        const uint32_t off = woff[c];
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, off, (uint32_t)s * wstep + (uint32_t)hl * 1024u, 0);
+        wn[c][hl] = __builtin_bit_cast(bf16x8, v);
+      }
   };
 
-  f32x4 acc[4][NCT];
+  f32x4 acc[8][CTW];
 #pragma unroll
-  for (int pt = 0; pt < 4; ++pt)
+  for (int pt = 0; pt < 8; ++pt)
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) acc[pt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < CTW; ++ct) acc[pt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // B-fragment unit of (pixel-tile pt, tap 0,0) for this lane
-  int bunit[4];
-#pragma unroll
-  for (int pt = 0; pt < 4; ++pt) bunit[pt] = lg * PS + (wave * 2 + (pt >> 1)) * IW + (pt & 1) * 16 + li;
+  const int bunit0 = lg * PS + (wpx * 4) * IW + li;
 
-  load_act(0);
-  load_w(0);
-  int cur = 1;
-  for (int q = 0; q < nchunks; ++q) {
-    __syncthreads();  // every wave is done reading the previous chunk's tile and weights
+  // ---- persistent loop over this workgroup's tiles; the (tile, chunk) stream is prefetched one item ahead,
+  //      so only the very first tile of a workgroup exposes its global-load latency ----
+  int tile = blockIdx.x;
+  if (tile >= num_tiles) return;
+  load_w(0);  // weights first: vmcnt retires in order
+  set_fill_tile(tile);
+  load_act(0, true);
+  int q = 0;
+  while (true) {
+    __syncthreads();  // every wave is done reading the previous item's halo tile
     store_act();
-    cur ^= 1;
-    store_w(cur);
     __syncthreads();
-    if (q + 1 < nchunks) load_act(q + 1);
+    const bool last_chunk = (q == nchunks - 1);
+    const int ntile = tile + (int)gridDim.x;
+    const bool more = !last_chunk || (ntile < num_tiles);
+    // software pipeline over the 8 pixel tiles: fragments of (t, pt+1) are read from LDS while (t, pt) multiplies
+    bf16x8 bh = *(const bf16x8*)&s_act[bunit0];
+    bf16x8 bl;
+    if (PROD == 3) bl = *(const bf16x8*)&s_act[ACT_UNITS + bunit0];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const int s = q * T + t;
-      if (s + 1 < nsteps) load_w(s + 1);
-      const int dy = t / KS;
-      const int dx = t - dy * KS;
-      const bf16x8* wf = (const bf16x8*)&s_w[cur * W_UNITS];
-      bf16x8 wa[NCT][NHL];
 #pragma unroll
-      for (int ct = 0; ct < NCT; ++ct)
+      for (int c = 0; c < CTW; ++c)
 #pragma unroll
-        for (int hl = 0; hl < NHL; ++hl) wa[ct][hl] = wf[(ct * NHL + hl) * 64 + lane];
+        for (int hl = 0; hl < NHL; ++hl) wc[c][hl] = wn[c][hl];
+      load_w(s + 1 < nsteps ? s + 1 : 0);  // next tap's weights (wraps to step 0 of the next tile)
+      if (t == 0) {
+        if (last_chunk) set_fill_tile(ntile);
+        load_act(last_chunk ? 0 : q + 1, more);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int pt = 0; pt < 4; ++pt) {
-        const int u = bunit[pt] + dy * IW + dx;
-        const bf16x8 bh = *(const bf16x8*)&s_act[u];
+      for (int pt = 0; pt < 8; ++pt) {
+        // next fragment: (t, pt+1), or (t+1, 0) across the tap boundary
+        const int nt = (pt == 7) ? t + 1 : t;
+        const int npt = (pt == 7) ? 0 : pt + 1;
+        bf16x8 nbh = bh, nbl = bh;
+        if (nt < T) {
+          const int ndy = nt / KS, ndx = nt - (nt / KS) * KS;
+          const int u = bunit0 + ((npt >> 1) + ndy) * IW + (npt & 1) * 16 + ndx;
+          nbh = *(const bf16x8*)&s_act[u];
+          if (PROD == 3) nbl = *(const bf16x8*)&s_act[ACT_UNITS + u];
+        }
         if (PROD == 3) {
-          const bf16x8 bl = *(const bf16x8*)&s_act[ACT_UNITS + u];
 #pragma unroll
-          for (int ct = 0; ct < NCT; ++ct) {
-            acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ct][NHL - 1], bh, acc[pt][ct], 0, 0, 0);
-            acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ct][0], bl, acc[pt][ct], 0, 0, 0);
-            acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ct][0], bh, acc[pt][ct], 0, 0, 0);
+          for (int ct = 0; ct < CTW; ++ct) {
+            acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ct][NHL - 1], bh, acc[pt][ct], 0, 0, 0);
+            acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ct][0], bl, acc[pt][ct], 0, 0, 0);
+            acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ct][0], bh, acc[pt][ct], 0, 0, 0);
           }
         } else {
 #pragma unroll
-          for (int ct = 0; ct < NCT; ++ct)
-            acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ct][0], bh, acc[pt][ct], 0, 0, 0);
+          for (int ct = 0; ct < CTW; ++ct)
+            acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ct][0], bh, acc[pt][ct], 0, 0, 0);
         }
-      }
-      if (t + 1 < T) {
-        store_w(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        bh = nbh;
+        if (PROD == 3) bl = nbl;
+        // issue order inside the step: the next fragment reads first, then this step's MFMAs (the reads then have
+        // the whole MFMA group to land; the waits become counted lgkmcnt(NHL))
+        __builtin_amdgcn_sched_group_barrier(0x100, NHL, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, (PROD == 3 ? 3 : 1) * CTW, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-  }
-
-  // ---------------- epilogue ----------------
-  const int64_t HW = (int64_t)p.H * p.W;
-  const int p4 = (p.cout + 3) >> 2;
-  const int ps = p.pixel_shuffle > 1 ? p.pixel_shuffle : 1;
-#pragma unroll
-  for (int pt = 0; pt < 4; ++pt) {
-    const int y = y0 + wave * 2 + (pt >> 1);
-    const int x = x0 + (pt & 1) * 16 + li;
-    if (y >= p.H || x >= p.W) continue;
-    const int64_t pix = (int64_t)y * p.W + x;
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-      const int c0 = (slab * NCT + ct) * 16 + lg * 4;
-      if (c0 >= ((p.cout + 7) & ~7)) continue;  // no plane / no f32 group holds these channels
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = c0 + r;
-        float b = (p.bias != nullptr && c < p.cout) ? p.bias[c] : 0.f;
-        v[r] = acc[pt][ct][r] + b;
-      }
-      const bool has_f32grp = c0 < (p4 << 2);
-      const int64_t f32idx = (((int64_t)n * p4 + (c0 >> 2)) * HW + pix);
-      if (p.act == RSA_ACT_SPAB_GATE) {
-        f32x4 rr = {0.f, 0.f, 0.f, 0.f};
-        if (has_f32grp) rr = ((const f32x4*)p.res1)[f32idx];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sg = 1.f / (1.f + expf(-v[r]));
-          v[r] = (v[r] + rr[r]) * (sg - 0.5f);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act, p.act_param);
-        if (p.res1 != nullptr && has_f32grp) {
-          const f32x4 rr = ((const f32x4*)p.res1)[f32idx];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + rr[r];
-        }
-      }
-      if (p.res2 != nullptr && has_f32grp) {
-        const f32x4 rr = ((const f32x4*)p.res2)[f32idx];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] * p.beta + rr[r];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (c0 + r >= p.cout) v[r] = 0.f;
-
-      if (p.out_hi != nullptr) {
-        const int64_t unit = (int64_t)n * p.out_batch_stride + (int64_t)(p.out_plane_off + (c0 >> 3)) * p.out_plane_stride + pix;
-        split_store(p.out_hi, p.out_lo, unit, (c0 >> 2) & 1, v);
-      }
-      if (p.out_f32 != nullptr && has_f32grp) {
-        ((f32x4*)p.out_f32)[f32idx] = (f32x4){v[0], v[1], v[2], v[3]};
-      }
-      if (p.out_nchw != nullptr) {
-        const int oc_total = p.cout / (ps * ps);
-        const int64_t oH = (int64_t)p.H * ps, oW = (int64_t)p.W * ps;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = c0 + r;
-          if (c >= p.cout) continue;
-          const int oc = c / (ps * ps);
-          const int rem = c - oc * ps * ps;
-          const int ii = rem / ps;
-          const int jj = rem - ii * ps;
-          float o = v[r] * p.out_scale;
-          if (p.out_shift != nullptr) o += p.out_shift[oc];
-          const int64_t idx = (((int64_t)n * oc_total + oc) * oH + ((int64_t)y * ps + ii)) * oW + ((int64_t)x * ps + jj);
-          if (p.out_dtype == RSA_F32)
-            ((float*)p.out_nchw)[idx] = o;
-          else if (p.out_dtype == RSA_F16)
-            ((_Float16*)p.out_nchw)[idx] = (_Float16)o;
-          else
-            ((__bf16*)p.out_nchw)[idx] = (__bf16)o;
-        }
-      }
+    if (!last_chunk) {
+      ++q;
+      continue;
     }
+    // ---- tile finished: epilogue for `tile`, then move on (next tile's first chunk is already in flight) ----
+    {
+      const int n = tile / tiles_img;
+      const int tr = tile - n * tiles_img;
+      const int ty = tr / tiles_x;
+      const int tx = tr - ty * tiles_x;
+      epilogue<NCT, CTW, OUTK>(p, acc, n, ty * TH, tx * TW, slab, wct, wpx, li, lg);
+    }
+#pragma unroll
+    for (int pt = 0; pt < 8; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < CTW; ++ct) acc[pt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    tile = ntile;
+    q = 0;
+    if (tile >= num_tiles) break;
   }
 }
 
-template <int KS, int NCT, int PROD, int UP>
+template <int KS, int NCT, int PROD, int UP, int OUTK>
 static int launch_one(const rsa_conv_params& p, hipStream_t stream) {
-  const int tiles_x = (p.W + TW - 1) / TW;
-  const int tiles_y = (p.H + TH - 1) / TH;
+  using G = Geo<KS, NCT>;
+  const int tiles_x = (p.W + G::TW - 1) / G::TW;
+  const int tiles_y = (p.H + G::TH - 1) / G::TH;
   const int ct_total = (p.cout + 15) / 16;
   const int slabs = (ct_total + NCT - 1) / NCT;
-  dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)slabs, (unsigned)p.batch);
-  hipLaunchKernelGGL((conv_kernel<KS, NCT, PROD, UP>), grid, dim3(NTHREADS), 0, stream, p);
+  const int64_t num_tiles = (int64_t)tiles_x * tiles_y * p.batch;
+  if (num_tiles > 0x7fffffff) return RSA_E_UNSUPPORTED;
+  // persistent workgroups: as many as the chip keeps resident (queried once per instantiation), strided over the tiles
+  static int resident = 0;
+  if (resident == 0) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_kernel<KS, NCT, PROD, UP, OUTK>, NTHREADS, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipGetLastError();
+    resident = per_cu * prop.multiProcessorCount;
+  }
+  int gx = resident / slabs;
+  if (gx < 1) gx = 1;
+  if (gx > num_tiles) gx = (int)num_tiles;
+  dim3 grid((unsigned)gx, (unsigned)slabs, 1);
+  hipLaunchKernelGGL((conv_kernel<KS, NCT, PROD, UP, OUTK>), grid, dim3(NTHREADS), 0, stream, p);
   return (int)hipGetLastError();
+}
+
+template <int KS, int PROD, int UP, int OUTK>
+static int launch_nct2(const rsa_conv_params& p, int nct, hipStream_t stream) {
+  switch (nct) {
+    case 1:
+      return launch_one<KS, 1, PROD, UP, OUTK>(p, stream);
+    case 2:
+      return launch_one<KS, 2, PROD, UP, OUTK>(p, stream);
+    case 3:
+      return launch_one<KS, 3, PROD, UP, OUTK>(p, stream);
+    default:
+      return launch_one<KS, 4, PROD, UP, OUTK>(p, stream);
+  }
 }
 
 template <int KS, int PROD, int UP>
 static int launch_nct(const rsa_conv_params& p, int nct, hipStream_t stream) {
-  switch (nct) {
-    case 1:
-      return launch_one<KS, 1, PROD, UP>(p, stream);
-    case 2:
-      return launch_one<KS, 2, PROD, UP>(p, stream);
-    case 3:
-      return launch_one<KS, 3, PROD, UP>(p, stream);
-    default:
-      return launch_one<KS, 4, PROD, UP>(p, stream);
-  }
+  return p.out_nchw != nullptr ? launch_nct2<KS, PROD, UP, 1>(p, nct, stream) : launch_nct2<KS, PROD, UP, 0>(p, nct, stream);
 }
 
 int conv_nct(int cout) {
@@ -375,8 +496,13 @@ int conv_launch(const rsa_conv_params& p, hipStream_t stream) {
   if (((uintptr_t)p.in_hi | (uintptr_t)p.in_lo | (uintptr_t)p.w_packed | (uintptr_t)p.out_hi | (uintptr_t)p.out_lo | (uintptr_t)p.out_f32 |
        (uintptr_t)p.res1 | (uintptr_t)p.res2) & 15)
     return set_error(RSA_E_ALIGN, "conv: pointers must be 16-byte aligned");
-  if (p.in_plane_stride * 4 >= (int64_t)1 << 32) return set_error(RSA_E_UNSUPPORTED, "conv: input plane too large for 32-bit unit offsets; band the image");
+  if (p.in_plane_stride * 64 >= (int64_t)1 << 32) return set_error(RSA_E_UNSUPPORTED, "conv: input plane too large for a 4-plane buffer descriptor (>= 64 Mpx); band the image");
+  if (p.out_plane_stride * 32 >= (int64_t)1 << 32 || (int64_t)p.H * p.W * 64 >= (int64_t)1 << 32)
+    return set_error(RSA_E_UNSUPPORTED, "conv: output plane too large for 32-bit lane offsets; band the image");
+  if ((uintptr_t)p.bias & 15) return set_error(RSA_E_ALIGN, "conv: bias must be 16-byte aligned (and padded to a multiple of 16 floats)");
   if (p.out_nchw != nullptr) {
+    if (p.out_hi != nullptr || p.out_f32 != nullptr || p.res1 != nullptr || p.res2 != nullptr || p.act == RSA_ACT_SPAB_GATE)
+      return set_error(RSA_E_UNSUPPORTED, "conv: out_nchw is a final store: no plane/f32 outputs or residuals with it");
     const int ps = p.pixel_shuffle > 1 ? p.pixel_shuffle : 1;
     if (p.cout % (ps * ps) != 0) return set_error(RSA_E_ARG, "conv: cout not divisible by pixel_shuffle^2");
     if (p.out_dtype < RSA_F32 || p.out_dtype > RSA_BF16) return set_error(RSA_E_ARG, "conv: bad out_dtype");

@@ -58,6 +58,27 @@ class ConvParams(C.Structure):
     ]
 
 
+class DySampleParams(C.Structure):
+    """Mirror of ``struct rsa_dysample_params``."""
+
+    _fields_ = [
+        ('batch', C.c_int32),
+        ('H', C.c_int32),
+        ('W', C.c_int32),
+        ('C', C.c_int32),
+        ('groups', C.c_int32),
+        ('scale', C.c_int32),
+        ('out_ch', C.c_int32),
+        ('x_f32', C.c_void_p),
+        ('offscope', C.c_void_p),
+        ('init_pos', C.c_void_p),
+        ('end_w', C.c_void_p),
+        ('end_b', C.c_void_p),
+        ('out_nchw', C.c_void_p),
+        ('out_dtype', C.c_int32),
+    ]
+
+
 # every symbol include/resselt_amd.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = (
     'rsa_version',
@@ -68,6 +89,7 @@ EXPORTS = (
     'rsa_packed_weight_bytes',
     'rsa_nchw_to_planes',
     'rsa_planes_to_nchw',
+    'rsa_dysample',
 )
 
 
@@ -109,6 +131,8 @@ def load() -> C.CDLL:
         C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
     ]  # fmt: skip
     lib.rsa_planes_to_nchw.restype = C.c_int
+    lib.rsa_dysample.argtypes = [C.POINTER(DySampleParams), C.c_void_p]
+    lib.rsa_dysample.restype = C.c_int
     _lib = lib
     return lib
 

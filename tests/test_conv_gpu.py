@@ -56,8 +56,9 @@ def test_conv_plain(device, products, n, cin, cout, h, w, k):
     out = tensors.Planes.empty(n, (cout + 7) // 8, h, w, device)
     of32 = tensors.empty_f32map(n, cout, h, w, device)
     onchw = torch.empty((n, cout, h, w), dtype=torch.float32, device=device)
-    p = ops.conv_params(wts, xin, h, w, out=out, out_f32=of32, out_nchw=onchw)
-    ops.run_convs([p], device)
+    p = ops.conv_params(wts, xin, h, w, out=out, out_f32=of32)
+    p2 = ops.conv_params(wts, xin, h, w, out_nchw=onchw)  # final-store instantiation
+    ops.run_convs([p, p2], device)
     torch.cuda.synchronize()
     _check(onchw, ref, products, 'out_nchw')
     _check(tensors.f32map_to_nchw(of32, cout), ref, products, 'out_f32')
