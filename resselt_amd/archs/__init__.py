@@ -6,7 +6,10 @@ this build registers the families of the hot path: ESRGAN/RRDBNe
 
 from ..registry import Registry
 from .esrgan import ESRGANArch
+from .span import SPANArch
+from .spanplus import SpanPlusArch
 
 internal_registry = Registry()
-for _arch in (ESRGANArch,):
+# relative order follows the reference's registry walk (tests/golden/registry_claims.npz): ESRGAN, spanplus, ..., SPAN
+for _arch in (ESRGANArch, SpanPlusArch, SPANArch):
     internal_registry.add(_arch())
