@@ -132,12 +132,13 @@ int rsa_conv_cout_tiles(int32_t cout);
  */
 
 /*
- * Plain NCHW tensor -> split planes, with per-channel affine  v = (x - mean[c]) * scale.
- * Replaces the implicit NCHW read of the first conv and `(x - mean) * img_range`
- * (archs/span/arch.py:232-234, archs/swinir/arch.py:966-967).  Channels padded to 8 with zeros.
+ * Plain NCHW tensor [N][C][src_h][src_w] -> split planes of size H x W, with per-channel affine v = (x - mean[c]) * scale.
+ * Replaces the implicit NCHW read of the first conv, `(x - mean) * img_range` (archs/span/arch.py:232-234,
+ * archs/swinir/arch.py:966-967) and, when H > src_h or W > src_w, the right/bottom REFLECT padding of
+ * pad_to_multiple (utilities/padding.py:24-29; SwinIR.check_image_size).  Channels padded to 8 with zeros.
  */
-int rsa_nchw_to_planes(const void* x, int32_t dtype, int32_t batch, int32_t C, int32_t H, int32_t W, const float* mean,
-                       float scale, void* out_hi, void* out_lo, int64_t out_plane_stride, int64_t out_batch_stride,
+int rsa_nchw_to_planes(const void* x, int32_t dtype, int32_t batch, int32_t C, int32_t H, int32_t W, int32_t src_h, int32_t src_w,
+                       const float* mean, float scale, void* out_hi, void* out_lo, int64_t out_plane_stride, int64_t out_batch_stride,
                        void* stream);
 
 /* split planes / f32 NCHW4c -> plain NCHW (debug + parity of intermediates) */
@@ -166,6 +167,57 @@ typedef struct rsa_dysample_params {
 } rsa_dysample_params;
 
 int rsa_dysample(const rsa_dysample_params* p, void* stream);
+
+/*
+ * nn.LayerNorm over the channel axis of a token map (tokens = pixels).
+ * Replaces norm1 / norm2 / patch_embed.norm / norm of resselt/archs/swinir/arch.py:306,333,640,959 together with the
+ * flatten/transpose/view round trips of PatchEmbed / PatchUnEmbed (:638-642,679-682): the map never changes layout.
+ */
+typedef struct rsa_layernorm_params {
+  int32_t batch;
+  int32_t H, W;
+  int32_t C;               /* channels normalised over */
+  float eps;
+  const float* x_f32;      /* f32 NCHW4c [N][ceil(C/4)][H][W][4] */
+  const float* gamma;      /* [C] */
+  const float* beta;       /* [C] */
+  void* out_hi;            /* split planes [N][ceil(C/8)][H][W][8], tail channels zeroed; may be NULL */
+  void* out_lo;            /* may be NULL */
+  int64_t out_plane_stride; /* 16-byte units */
+  int64_t out_batch_stride;
+  float* out_f32;          /* optional f32 NCHW4c copy of the result */
+} rsa_layernorm_params;
+
+int rsa_layernorm(const rsa_layernorm_params* p, void* stream);
+
+/*
+ * (Shifted-)window multi-head self-attention core: softmax(q k^T + B[idx] (+ mask)) v for every window and head.
+ * Replaces, between the qkv and proj Linear layers, resselt/archs/swinir/arch.py:141-170 (WindowAttention.forward) and the
+ * torch.roll / window_partition / window_reverse / calculate_mask data movement of SwinTransformerBlock.forward (:295-335).
+ * Input planes: [(which*heads + head)*4, +4) hold 32 channels (head_dim zero-padded) of q (pre-scaled), k, v.
+ * bias_frag: relative_position_bias_table gathered by relative_position_index and laid out in accumulator-fragment order
+ *            [head][query tile 2][key tile 2][lane 64][16] f32 (resselt_amd/archs/swinir/arch.py::bias_fragments);
+ *            key slots beyond window^2 carry -1e30.
+ */
+typedef struct rsa_window_attn_params {
+  int32_t batch;
+  int32_t H, W;            /* multiples of `window` */
+  int32_t heads;
+  int32_t window;          /* <= 8 */
+  int32_t shift;           /* 0 or window/2 */
+  int32_t products;        /* 1 or 3 */
+  const void* qkv_hi;
+  const void* qkv_lo;      /* may be NULL when products == 1 */
+  int64_t qkv_plane_stride; /* 16-byte units */
+  int64_t qkv_batch_stride;
+  const float* bias_frag;
+  void* out_hi;            /* planes [head*4, +4) : attention output, head_dim padded to 32 */
+  void* out_lo;
+  int64_t out_plane_stride;
+  int64_t out_batch_stride;
+} rsa_window_attn_params;
+
+int rsa_window_attention(const rsa_window_attn_params* p, void* stream);
 
 /* version / errors */
 int rsa_version(void);

@@ -8,8 +8,9 @@ from ..registry import Registry
 from .esrgan import ESRGANArch
 from .span import SPANArch
 from .spanplus import SpanPlusArch
+from .swinir import SwinIRArch
 
 internal_registry = Registry()
-# relative order follows the reference's registry walk (tests/golden/registry_claims.npz): ESRGAN, spanplus, ..., SPAN
-for _arch in (ESRGANArch, SpanPlusArch, SPANArch):
+# relative order follows the reference's registry walk (tests/golden/registry_claims.npz): ESRGAN, spanplus, SwinIR, ..., SPAN
+for _arch in (ESRGANArch, SpanPlusArch, SwinIRArch, SPANArch):
     internal_registry.add(_arch())

@@ -1,0 +1,438 @@
+"""SwinIR on the MI355X engine (reference module: ``resselt/archs/swinir/arch.py:735-1015``).
+
+Tokens are pixels and never change layout: the f32 NCHW4c map is the residual stream, LayerNorm writes split planes,
+every ``nn.Linear`` is a k1 convolution of the conv engine (GELU / residual adds in its epilogue), the attention core
+runs in ``rsa_window_attention`` with roll / window partition / mask / relative-position bias as index arithmetic, and
+the 1conv/3conv residual tails and the upsampling head are ordinary fused convolutions.
+
+Weight re-layout at pack time (never per forward):
+  * qkv rows are regrouped per head and zero-padded to 32 channels, q rows pre-multiplied by head_dim**-0.5;
+    proj columns are padded the same way;
+  * ``relative_position_bias_table[relative_position_index]`` is gathered once into accumulator-fragment order.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from ...engine import lib as L
+from ...engine import ops
+from ...engine.base import EngineModule, Plan
+from ...engine.paramtree import build_param_tree
+
+RGB_MEAN = (0.4488, 0.4371, 0.4040)  # resselt/archs/swinir/arch.py:788-790
+HEAD_PAD = 32  # channels each head occupies in the attention planes
+
+
+def relative_position_index(window: int) -> torch.Tensor:
+    """The registered buffer of WindowAttention (arch.py:111-122)."""
+    coords = torch.stack(torch.meshgrid([torch.arange(window), torch.arange(window)], indexing='ij')).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += window - 1
+    rel[:, :, 1] += window - 1
+    rel[:, :, 0] *= 2 * window - 1
+    return rel.sum(-1)
+
+
+def shift_attn_mask(img_size: int, window: int) -> torch.Tensor:
+    """The registered ``attn_mask`` buffer of shifted blocks (arch.py:268-293); kept for state_dict parity only."""
+    s = window // 2
+    img = torch.zeros(1, img_size, img_size, 1)
+    cnt = 0
+    for hs in (slice(0, -window), slice(-window, -s), slice(-s, None)):
+        for ws in (slice(0, -window), slice(-window, -s), slice(-s, None)):
+            img[:, hs, ws, :] = cnt
+            cnt += 1
+    nw = img_size // window
+    mw = img.view(1, nw, window, nw, window, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, window * window)
+    d = mw.unsqueeze(1) - mw.unsqueeze(2)
+    return torch.where(d != 0, torch.full_like(d, -100.0), torch.zeros_like(d))
+
+
+def bias_fragments(table: torch.Tensor, index: torch.Tensor, window: int) -> torch.Tensor:
+    """table[(2w-1)^2, heads] gathered by index[w^2, w^2] -> [heads][qt 2][kt 2][lane 64][16] f32 in the S^T accumulator order:
+    lane l, element r  <->  query 32*qt + (l & 31),  key 32*kt + (r & 3) + 8*(r >> 2) + 4*(l >> 5).  Padded keys get -1e30."""
+    n = window * window
+    heads = table.shape[1]
+    dense = torch.zeros((heads, 64, 64), dtype=torch.float32, device=table.device)
+    dense[:, :, n:] = -1e30
+    dense[:, :n, :n] = table.to(torch.float32)[index.reshape(-1).long()].reshape(n, n, heads).permute(2, 0, 1)
+    lane = torch.arange(64, device=table.device)
+    r = torch.arange(16, device=table.device)
+    q_in = (lane & 31)[:, None].expand(64, 16)
+    k_in = ((r & 3) + 8 * (r >> 2))[None, :] + 4 * (lane >> 5)[:, None]
+    out = torch.empty((heads, 2, 2, 64, 16), dtype=torch.float32, device=table.device)
+    for qt in range(2):
+        for kt in range(2):
+            out[:, qt, kt] = dense[:, 32 * qt + q_in, 32 * kt + k_in]
+    return out.contiguous()
+
+
+def regroup_qkv(w: torch.Tensor, b: torch.Tensor | None, heads: int) -> tuple[torch.Tensor, torch.Tensor]:
+    """[3C, C] -> [3*heads*32, C]: row (which, head, d) <- which*C + head*hd + d, zero rows for d >= hd; q rows scaled."""
+    c3, c = w.shape
+    hd = c // heads
+    wn = torch.zeros((3, heads, HEAD_PAD, c), dtype=torch.float32, device=w.device)
+    bn = torch.zeros((3, heads, HEAD_PAD), dtype=torch.float32, device=w.device)
+    wn[:, :, :hd] = w.to(torch.float32).reshape(3, heads, hd, c)
+    if b is not None:
+        bn[:, :, :hd] = b.to(torch.float32).reshape(3, heads, hd)
+    scale = hd**-0.5
+    wn[0] *= scale
+    bn[0] *= scale
+    return wn.reshape(3 * heads * HEAD_PAD, c), bn.reshape(-1)
+
+
+def regroup_proj(w: torch.Tensor, heads: int) -> torch.Tensor:
+    """[C, C] -> [C, heads*32]: column (head, d) <- head*hd + d."""
+    c = w.shape[0]
+    hd = w.shape[1] // heads
+    wn = torch.zeros((c, heads, HEAD_PAD), dtype=torch.float32, device=w.device)
+    wn[:, :, :hd] = w.to(torch.float32).reshape(c, heads, hd)
+    return wn.reshape(c, heads * HEAD_PAD)
+
+
+def swinir_param_shapes(in_ch, out_ch, embed_dim, depths, num_heads, window, mlp_ratio, upscale, upsampler, resi, img_size, patch_norm=True):
+    shapes: dict = {}
+    buffers: dict = {}
+    C_ = embed_dim
+    hidden = int(C_ * mlp_ratio)
+
+    def conv(name, co, ci, k):
+        shapes[f'{name}.weight'] = (co, ci, k, k)
+        shapes[f'{name}.bias'] = (co,)
+
+    def lin(name, co, ci):
+        shapes[f'{name}.weight'] = (co, ci)
+        shapes[f'{name}.bias'] = (co,)
+
+    def ln(name):
+        shapes[f'{name}.weight'] = (C_,)
+        shapes[f'{name}.bias'] = (C_,)
+
+    def resi_conv(name):
+        if resi == '1conv':
+            conv(name, C_, C_, 3)
+        else:
+            conv(f'{name}.0', C_ // 4, C_, 3)
+            conv(f'{name}.2', C_ // 4, C_ // 4, 1)
+            conv(f'{name}.4', C_, C_ // 4, 3)
+
+    conv('conv_first', C_, in_ch, 3)
+    if patch_norm:
+        ln('patch_embed.norm')
+    rp = relative_position_index(window)
+    mask = None
+    for i, depth in enumerate(depths):
+        for j in range(depth):
+            b = f'layers.{i}.residual_group.blocks.{j}'
+            if j % 2 == 1:
+                if mask is None:
+                    mask = shift_attn_mask(img_size, window)
+                buffers[f'{b}.attn_mask'] = mask
+            ln(f'{b}.norm1')
+            shapes[f'{b}.attn.relative_position_bias_table'] = ((2 * window - 1) ** 2, num_heads[i])
+            buffers[f'{b}.attn.relative_position_index'] = rp
+            lin(f'{b}.attn.qkv', 3 * C_, C_)
+            lin(f'{b}.attn.proj', C_, C_)
+            ln(f'{b}.norm2')
+            lin(f'{b}.mlp.fc1', hidden, C_)
+            lin(f'{b}.mlp.fc2', C_, hidden)
+        resi_conv(f'layers.{i}.conv')
+    ln('norm')
+    resi_conv('conv_after_body')
+    nf = 64
+    if upsampler == 'nearest+conv':
+        conv('conv_before_upsample.0', nf, C_, 3)
+        conv('conv_up1', nf, nf, 3)
+        if upscale in (4, 8):
+            conv('conv_up2', nf, nf, 3)
+        if upscale == 8:
+            conv('conv_up3', nf, nf, 3)
+        conv('conv_hr', nf, nf, 3)
+        conv('conv_last', out_ch, nf, 3)
+    elif upsampler == 'pixelshuffle':
+        conv('conv_before_upsample.0', nf, C_, 3)
+        if upscale == 3:
+            conv('upsample.0', 9 * nf, nf, 3)
+        elif upscale & (upscale - 1) == 0:
+            for u in range(int(math.log2(upscale))):
+                conv(f'upsample.{2 * u}', 4 * nf, nf, 3)
+        else:
+            raise ValueError(f'scale {upscale} is not supported. Supported scales: 2^n and 3.')
+        conv('conv_last', out_ch, nf, 3)
+    elif upsampler == 'pixelshuffledirect':
+        conv('upsample.0', upscale * upscale * out_ch, C_, 3)
+    else:
+        conv('conv_last', out_ch, C_, 3)
+    return shapes, buffers
+
+
+class SwinIR(EngineModule):
+    hyperparameters = {}
+
+    def __init__(self, *, img_size=64, patch_size=1, in_chans=3, embed_dim=96, depths=(6, 6, 6, 6), num_heads=(6, 6, 6, 6), window_size=7,
+                 mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1, ape=False,
+                 patch_norm=True, use_checkpoint=False, upscale=1, img_range=1.0, upsampler='', resi_connection='1conv',
+                 start_unshuffle=1) -> None:  # fmt: skip
+        super().__init__()
+        if patch_size != 1 or ape or not qkv_bias or qk_scale is not None:
+            raise NotImplementedError('SwinIR engine supports patch_size=1, ape=False, qkv_bias=True, default qk scale (what the loader builds)')
+        if start_unshuffle != 1:
+            raise NotImplementedError('start_unshuffle > 1 cannot load in the reference either (SURVEY.md §4 defect 6)')
+        if upsampler == '':
+            raise NotImplementedError("SwinIR denoising / JPEG heads (upsampler '') are outside this build's scope (SURVEY.md §8)")
+        if window_size > 8:
+            raise NotImplementedError('window_size must be <= 8 (64 tokens per window)')
+        if min(img_size, img_size) <= window_size:
+            raise NotImplementedError('img_size <= window_size changes the block geometry; not supported')
+        depths, num_heads = list(depths), list(num_heads)
+        if any(embed_dim % h or embed_dim // h > HEAD_PAD for h in num_heads):
+            raise NotImplementedError('head_dim must divide embed_dim and be <= 32')
+        if embed_dim % 4:
+            raise NotImplementedError('embed_dim must be a multiple of 4')
+        self.in_chans, self.out_chans = in_chans, in_chans
+        self.embed_dim, self.depths, self.num_heads = embed_dim, depths, num_heads
+        self.window_size, self.mlp_ratio = window_size, mlp_ratio
+        self.upscale, self.img_range, self.upsampler = upscale, img_range, upsampler
+        self.resi, self.patch_norm, self.img_size = resi_connection, patch_norm, img_size
+        shapes, buffers = swinir_param_shapes(in_chans, in_chans, embed_dim, depths, num_heads, window_size, mlp_ratio, upscale, upsampler,
+                                              resi_connection, img_size, patch_norm)  # fmt: skip
+        build_param_tree(self, shapes, buffers)
+
+    # ---------------------------------------------------------------- weights
+    def _pack(self, device, products):
+        sd = {k: v.detach().to(device) for k, v in self.state_dict().items()}
+        W: dict = {}
+
+        def conv(name):
+            W[name] = ops.ConvWeights.from_oihw(sd[f'{name}.weight'], sd.get(f'{name}.bias'), products, device=device)
+
+        def lin(name, w=None, b=None, cin_planes=None):
+            w = sd[f'{name}.weight'] if w is None else w
+            b = sd.get(f'{name}.bias') if b is None else b
+            W[name] = ops.ConvWeights.from_oihw(w[:, :, None, None], b, products, cin_planes=cin_planes, device=device)
+
+        def ln(name):
+            W[name] = (sd[f'{name}.weight'].float().contiguous(), sd[f'{name}.bias'].float().contiguous())
+
+        def resi_conv(name):
+            for sub in ([''] if self.resi == '1conv' else ['.0', '.2', '.4']):
+                conv(name + sub)
+
+        conv('conv_first')
+        if self.patch_norm:
+            ln('patch_embed.norm')
+        for i, depth in enumerate(self.depths):
+            heads = self.num_heads[i]
+            for j in range(depth):
+                b = f'layers.{i}.residual_group.blocks.{j}'
+                ln(f'{b}.norm1')
+                ln(f'{b}.norm2')
+                wq, bq = regroup_qkv(sd[f'{b}.attn.qkv.weight'], sd[f'{b}.attn.qkv.bias'], heads)
+                lin(f'{b}.attn.qkv', wq, bq)
+                lin(f'{b}.attn.proj', regroup_proj(sd[f'{b}.attn.proj.weight'], heads), sd[f'{b}.attn.proj.bias'], cin_planes=heads * HEAD_PAD // 8)
+                lin(f'{b}.mlp.fc1')
+                lin(f'{b}.mlp.fc2')
+                W[f'{b}.bias_frag'] = bias_fragments(sd[f'{b}.attn.relative_position_bias_table'], sd[f'{b}.attn.relative_position_index'],
+                                                     self.window_size)  # fmt: skip
+            resi_conv(f'layers.{i}.conv')
+        ln('norm')
+        resi_conv('conv_after_body')
+        for name in ('conv_before_upsample.0', 'conv_up1', 'conv_up2', 'conv_up3', 'conv_hr', 'conv_last', 'upsample.0', 'upsample.2',
+                     'upsample.4'):  # fmt: skip
+            if f'{name}.weight' in sd:
+                conv(name)
+        mean = torch.tensor(RGB_MEAN if self.in_chans == 3 else [0.0] * self.in_chans, dtype=torch.float32, device=device)
+        W['mean'] = mean
+        return W
+
+    def macs_per_input_pixel(self) -> int:
+        """Algorithmic MACs per (window-padded) input pixel: convs, Linear layers and the two attention contractions."""
+        C_, w = self.embed_dim, self.window_size
+        hidden = int(C_ * self.mlp_ratio)
+        nblocks = sum(self.depths)
+        macs = 9 * self.in_chans * C_
+        macs += nblocks * (3 * C_ * C_ + C_ * C_ + 2 * C_ * hidden + 2 * w * w * C_)
+        resi = 9 * C_ * C_ if self.resi == '1conv' else (9 * C_ * (C_ // 4) * 2 + (C_ // 4) ** 2)
+        macs += (len(self.depths) + 1) * resi
+        s = self.upscale
+        if self.upsampler == 'nearest+conv':
+            macs += 9 * C_ * 64
+            res = 1
+            for _ in range(int(math.log2(s))):
+                res *= 4
+                macs += 9 * 64 * 64 * res
+            macs += (9 * 64 * 64 + 9 * 64 * self.out_chans) * res
+        elif self.upsampler == 'pixelshuffle':
+            macs += 9 * C_ * 64
+            res = 1
+            if s == 3:
+                macs += 9 * 64 * 576
+                res = 9
+            else:
+                for _ in range(int(math.log2(s))):
+                    macs += 9 * 64 * 256 * res
+                    res *= 4
+            macs += 9 * 64 * self.out_chans * res
+        else:
+            macs += 9 * C_ * s * s * self.out_chans
+        return macs
+
+    # ---------------------------------------------------------------- plan
+    def _build_plan(self, plan: Plan, W, x_shape, dtype, products):
+        n, c, h0, w0 = x_shape
+        if c != self.in_chans:
+            raise RuntimeError(f'model expects {self.in_chans} input channels, got {c}')
+        win = self.window_size
+        H, Wd = h0 + (win - h0 % win) % win, w0 + (win - w0 % win) % win
+        if H - h0 >= h0 or Wd - w0 >= w0:
+            raise RuntimeError('input is too small for reflect padding to a multiple of the window size')
+        C_, s = self.embed_dim, self.upscale
+        hidden = int(C_ * self.mlp_ratio)
+        with_lo = products == 3
+        cp = (C_ + 7) // 8
+        dev = plan.device
+        lib = L.load()
+
+        x_pl = plan.planes(n, (c + 7) // 8, H, Wd, with_lo)
+        mean = W['mean']
+
+        def set_input(x):
+            # check_image_size (reflect pad to the window multiple) and (x - mean) * img_range, fused (arch.py:964-967)
+            ops.nchw_to_planes(x, x_pl, mean, self.img_range)
+
+        first = plan.f32map(n, C_, H, Wd)
+        pool = [plan.f32map(n, C_, H, Wd) for _ in range(4)]
+        a_pl = plan.planes(n, cp, H, Wd, with_lo)  # LayerNorm output / conv input
+        max_heads = max(self.num_heads)
+        qkv_pl = plan.planes(n, 3 * max_heads * HEAD_PAD // 8, H, Wd, with_lo)
+        o_pl = plan.planes(n, max_heads * HEAD_PAD // 8, H, Wd, with_lo)
+        hid_pl = plan.planes(n, (hidden + 7) // 8, H, Wd, with_lo)
+        body_pl = plan.planes(n, cp, H, Wd, with_lo)
+        q4_a = plan.planes(n, (C_ // 4 + 7) // 8, H, Wd, with_lo) if self.resi == '3conv' else None
+        q4_b = plan.planes(n, (C_ // 4 + 7) // 8, H, Wd, with_lo) if self.resi == '3conv' else None
+
+        def layernorm(name, x_f32, out_planes=None, out_f32=None):
+            g, b = W[name]
+            lp = L.LayerNormParams()
+            lp.batch, lp.H, lp.W, lp.C, lp.eps = n, H, Wd, C_, 1e-5
+            lp.x_f32, lp.gamma, lp.beta = x_f32.data_ptr(), g.data_ptr(), b.data_ptr()
+            if out_planes is not None:
+                lp.out_hi, lp.out_lo = out_planes.hi_ptr(), out_planes.lo_ptr()
+                lp.out_plane_stride, lp.out_batch_stride = out_planes.plane_stride, out_planes.batch_stride
+            lp.out_f32 = None if out_f32 is None else out_f32.data_ptr()
+            plan.call(lambda: L.check(lib.rsa_layernorm(C.byref(lp), C.c_void_p(ops.current_stream_ptr(dev))), 'rsa_layernorm'))
+            plan._n_launches = plan.n_launches() + 1
+
+        def attention(name, heads, shift):
+            ap = L.WindowAttnParams()
+            ap.batch, ap.H, ap.W, ap.heads, ap.window, ap.shift, ap.products = n, H, Wd, heads, win, shift, products
+            ap.qkv_hi, ap.qkv_lo = qkv_pl.hi_ptr(), qkv_pl.lo_ptr()
+            ap.qkv_plane_stride, ap.qkv_batch_stride = qkv_pl.plane_stride, qkv_pl.batch_stride
+            ap.bias_frag = W[f'{name}.bias_frag'].data_ptr()
+            ap.out_hi, ap.out_lo = o_pl.hi_ptr(), o_pl.lo_ptr()
+            ap.out_plane_stride, ap.out_batch_stride = o_pl.plane_stride, o_pl.batch_stride
+            plan.call(lambda: L.check(lib.rsa_window_attention(C.byref(ap), C.c_void_p(ops.current_stream_ptr(dev))), 'rsa_window_attention'))
+            plan._n_launches = plan.n_launches() + 1
+
+        def resi_conv(name, src_planes, res, out_f32=None, out_planes=None):
+            """1conv / 3conv tail (arch.py:562-574) + the residual add that follows it."""
+            if self.resi == '1conv':
+                plan.conv(ops.conv_params(W[name], src_planes, H, Wd, cin_planes=cp, res1=res, alpha=1.0, out_f32=out_f32, out=out_planes))
+            else:
+                lre = dict(act=L.ACT_LRELU, act_param=0.2)
+                plan.conv(ops.conv_params(W[f'{name}.0'], src_planes, H, Wd, cin_planes=cp, out=q4_a, **lre))
+                plan.conv(ops.conv_params(W[f'{name}.2'], q4_a, H, Wd, out=q4_b, **lre))
+                plan.conv(ops.conv_params(W[f'{name}.4'], q4_b, H, Wd, res1=res, alpha=1.0, out_f32=out_f32, out=out_planes))
+
+        plan.conv(ops.conv_params(W['conv_first'], x_pl, H, Wd, out_f32=first))
+        free = list(pool)
+        if self.patch_norm:
+            cur = free.pop()
+            layernorm('patch_embed.norm', first, out_f32=cur)
+        else:
+            cur = first
+        for i, depth in enumerate(self.depths):
+            heads = self.num_heads[i]
+            hp = heads * HEAD_PAD // 8
+            rstb_in = cur
+            for j in range(depth):
+                b = f'layers.{i}.residual_group.blocks.{j}'
+                shift = 0 if j % 2 == 0 else win // 2
+                layernorm(f'{b}.norm1', cur, out_planes=a_pl)
+                plan.conv(ops.conv_params(W[f'{b}.attn.qkv'], a_pl, H, Wd, cin_planes=cp, out=qkv_pl))
+                attention(b, heads, shift)
+                x1 = free.pop()
+                plan.conv(ops.conv_params(W[f'{b}.attn.proj'], o_pl, H, Wd, cin_planes=hp, res1=cur, alpha=1.0, out_f32=x1))
+                layernorm(f'{b}.norm2', x1, out_planes=a_pl)
+                plan.conv(ops.conv_params(W[f'{b}.mlp.fc1'], a_pl, H, Wd, cin_planes=cp, act=L.ACT_GELU, out=hid_pl))
+                x2 = free.pop()
+                last = j == depth - 1
+                plan.conv(ops.conv_params(W[f'{b}.mlp.fc2'], hid_pl, H, Wd, cin_planes=(hidden + 7) // 8, res1=x1, alpha=1.0, out_f32=x2,
+                                          out=body_pl if last else None))  # fmt: skip
+                if cur is not rstb_in and cur is not first:
+                    free.append(cur)
+                free.append(x1)
+                cur = x2
+            out = free.pop()
+            resi_conv(f'layers.{i}.conv', body_pl, rstb_in, out_f32=out)
+            if rstb_in is not first:
+                free.append(rstb_in)
+            if cur is not rstb_in:
+                free.append(cur)
+            cur = out
+        layernorm('norm', cur, out_planes=a_pl)
+        resi_conv('conv_after_body', a_pl, first, out_planes=body_pl)  # + conv_first output (arch.py:988)
+
+        out_shape = (n, self.out_chans, H * s, Wd * s)
+        out_buf = {'y': torch.empty(out_shape, dtype=dtype, device=dev)}
+        final = dict(out_scale=1.0 / self.img_range, out_shift=mean)  # x / img_range + mean (arch.py:1013)
+        lre = dict(act=L.ACT_LRELU, act_param=0.2)
+        if self.upsampler == 'nearest+conv':
+            y = plan.planes(n, 8, H, Wd, with_lo)
+            plan.conv(ops.conv_params(W['conv_before_upsample.0'], body_pl, H, Wd, cin_planes=cp, act=L.ACT_LRELU, act_param=0.01, out=y))
+            hh, ww = H, Wd
+            for u in range(1, int(math.log2(s)) + 1):
+                hh, ww = hh * 2, ww * 2
+                ny = plan.planes(n, 8, hh, ww, with_lo)
+                plan.conv(ops.conv_params(W[f'conv_up{u}'], y, hh, ww, upsample2x=True, out=ny, **lre))
+                y = ny
+            hr = plan.planes(n, 8, hh, ww, with_lo)
+            plan.conv(ops.conv_params(W['conv_hr'], y, hh, ww, out=hr, **lre))
+            plan.conv(ops.conv_params(W['conv_last'], hr, hh, ww, out_nchw=out_buf['y'], **final))
+        elif self.upsampler == 'pixelshuffle':
+            y = plan.planes(n, 8, H, Wd, with_lo)
+            plan.conv(ops.conv_params(W['conv_before_upsample.0'], body_pl, H, Wd, cin_planes=cp, act=L.ACT_LRELU, act_param=0.01, out=y))
+            hh, ww = H, Wd
+            i = 0
+            while f'upsample.{i}' in W:
+                r = math.isqrt(W[f'upsample.{i}'].cout // 64)
+                shuffled = torch.empty((n, 64, hh * r, ww * r), dtype=torch.float32, device=dev)
+                plan.keep.append(shuffled)
+                plan.conv(ops.conv_params(W[f'upsample.{i}'], y, hh, ww, out_nchw=shuffled, pixel_shuffle=r))
+                hh, ww = hh * r, ww * r
+                ny = plan.planes(n, 8, hh, ww, with_lo)
+                plan.call(lambda src=shuffled, dst=ny: ops.nchw_to_planes(src, dst))
+                y = ny
+                i += 2
+            plan.conv(ops.conv_params(W['conv_last'], y, hh, ww, out_nchw=out_buf['y'], **final))
+        else:  # pixelshuffledirect
+            plan.conv(ops.conv_params(W['upsample.0'], body_pl, H, Wd, cin_planes=cp, out_nchw=out_buf['y'], pixel_shuffle=s, **final))
+        arr = plan.flush()
+        last_entry = arr[len(arr) - 1]
+
+        def prepare_output():
+            if 'y' not in out_buf:
+                out_buf['y'] = torch.empty(out_shape, dtype=dtype, device=dev)
+            last_entry.out_nchw = out_buf['y'].data_ptr()
+
+        plan.steps.insert(len(plan.steps) - 1, prepare_output)
+
+        def get_output():
+            return out_buf.pop('y')[:, :, : h0 * s, : w0 * s]
+
+        return set_input, get_output

@@ -28,23 +28,30 @@ __device__ __forceinline__ float ld_as_float(const void* p, int64_t i) {
 }
 
 // one thread per (n, plane, y, x) unit: gathers 8 channels of one pixel from the plain NCHW tensor
-__global__ void nchw_to_planes_kernel(const void* x, int dtype, int batch, int C, int H, int W, const float* mean, float scale,
-                                      void* out_hi, void* out_lo, int64_t plane_stride, int64_t batch_stride) {
+// (H, W) = size of the planes; (srcH, srcW) <= (H, W) = size of x: rows/columns past the source are filled by REFLECTION
+// (F.pad(..., 'reflect') to the right/bottom, resselt/utilities/padding.py:24-29 as used by SwinIR.check_image_size)
+__global__ void nchw_to_planes_kernel(const void* x, int dtype, int batch, int C, int H, int W, int srcH, int srcW, const float* mean,
+                                      float scale, void* out_hi, void* out_lo, int64_t plane_stride, int64_t batch_stride) {
   const int planes = (C + 7) >> 3;
   const int64_t HW = (int64_t)H * W;
+  const int64_t sHW = (int64_t)srcH * srcW;
   const int64_t total = (int64_t)batch * planes * HW;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t pix = idx % HW;
     const int64_t t = idx / HW;
     const int pl = (int)(t % planes);
     const int n = (int)(t / planes);
+    int sy = (int)(pix / W), sx = (int)(pix % W);
+    if (sy >= srcH) sy = 2 * (srcH - 1) - sy;
+    if (sx >= srcW) sx = 2 * (srcW - 1) - sx;
+    const int64_t spix = (int64_t)sy * srcW + sx;
     bf16x8 h, l;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = pl * 8 + j;
       float v = 0.f;
       if (c < C) {
-        const int64_t src = ((int64_t)n * C + c) * HW + pix;
+        const int64_t src = ((int64_t)n * C + c) * sHW + spix;
         if (dtype == RSA_F32)
           v = ld_as_float<float>(x, src);
         else if (dtype == RSA_F16)
@@ -125,14 +132,17 @@ int64_t rsa_packed_weight_bytes(int32_t cout, int32_t cin_planes, int32_t ksize,
   return chunks * ksize * ksize * ct * nhl * 64 * 16;
 }
 
-int rsa_nchw_to_planes(const void* x, int32_t dtype, int32_t batch, int32_t C, int32_t H, int32_t W, const float* mean, float scale,
-                       void* out_hi, void* out_lo, int64_t out_plane_stride, int64_t out_batch_stride, void* stream) {
+int rsa_nchw_to_planes(const void* x, int32_t dtype, int32_t batch, int32_t C, int32_t H, int32_t W, int32_t src_h, int32_t src_w,
+                       const float* mean, float scale, void* out_hi, void* out_lo, int64_t out_plane_stride, int64_t out_batch_stride,
+                       void* stream) {
   if (x == nullptr || out_hi == nullptr || batch < 1 || C < 1 || H < 1 || W < 1) return rsa::set_error(RSA_E_ARG, "nchw_to_planes: bad argument");
+  if (src_h < 1 || src_w < 1 || src_h > H || src_w > W || H - src_h >= src_h || W - src_w >= src_w)
+    return rsa::set_error(RSA_E_ARG, "nchw_to_planes: source size must satisfy src <= plane size < 2*src (reflect padding)");
   if (dtype < RSA_F32 || dtype > RSA_BF16) return rsa::set_error(RSA_E_ARG, "nchw_to_planes: bad dtype");
   if (((uintptr_t)out_hi | (uintptr_t)out_lo) & 15) return rsa::set_error(RSA_E_ALIGN, "nchw_to_planes: outputs must be 16-byte aligned");
   const int64_t total = (int64_t)batch * ((C + 7) / 8) * H * W;
   hipLaunchKernelGGL(rsa::nchw_to_planes_kernel, dim3(rsa::grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, dtype, batch, C, H, W,
-                     mean, scale, out_hi, out_lo, out_plane_stride, out_batch_stride);
+                     src_h, src_w, mean, scale, out_hi, out_lo, out_plane_stride, out_batch_stride);
   const int rc = (int)hipGetLastError();
   return rc ? rsa::set_error(rc, "nchw_to_planes: launch failed") : RSA_OK;
 }

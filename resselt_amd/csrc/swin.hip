@@ -1,0 +1,347 @@
+// swin.hip — the two non-convolution kernels of the SwinIR path:
+//   rsa_layernorm         nn.LayerNorm over channels of a token map        (reference archs/swinir/arch.py:306,333,959)
+//   rsa_window_attention  (shifted) window multi-head self-attention core  (reference archs/swinir/arch.py:133-173 between
+//                         the qkv and proj Linear layers, plus torch.roll / window_partition / window_reverse /
+//                         calculate_mask of SwinTransformerBlock.forward :295-335, which become index arithmetic)
+//
+// Tokens are pixels: the residual stream is the f32 NCHW4c map, Linear layers are k1 convolutions of conv_mfma.hip.
+// The qkv projection is packed so that every head owns 32 channels (head_dim zero-padded to 32 = 4 planes = one MFMA K):
+//   planes [ (which*heads + head)*4 , +4 )  with which = 0 q (pre-scaled), 1 k, 2 v.
+//
+// One wave = one (window, head).  With the key index on MFMA rows:
+//   S^T = K Q^T     v_mfma_f32_32x32x16_bf16, A = K fragment, B = Q fragment: both are plain 16-byte unit loads
+//   softmax         every lane owns ONE query column: row max / row sum are in-lane loops + one exchange with lane^32
+//   O^T = V^T P^T   the accumulator tile of S^T is already the B operand (rows = keys = the summed index); V^T comes
+//                   from a row-major LDS image of V through ds_read_b64_tr_b16 (hardware transpose read)
+//   store           O^T's accumulator layout gives each lane 4 consecutive channels of its token: 8-byte plane writes
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+#include "resselt_amd.h"
+
+namespace rsa {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+__global__ __launch_bounds__(256) void layernorm_kernel(const rsa_layernorm_params p) {
+  const int64_t HW = (int64_t)p.H * p.W;
+  const int64_t total = (int64_t)p.batch * HW;
+  const int p4 = (p.C + 3) >> 2;
+  const int planes = (p.C + 7) >> 3;
+  const float inv_c = 1.f / (float)p.C;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = idx % HW;
+    const int n = (int)(idx / HW);
+    const f32x4* x = (const f32x4*)p.x_f32 + (int64_t)n * p4 * HW + pix;
+    // two-pass mean / biased variance (matches ATen's numerics to rounding), third pass normalises
+    float sum = 0.f;
+    for (int g = 0; g < p4; ++g) {
+      const f32x4 v = x[(int64_t)g * HW];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (g * 4 + r < p.C) sum += v[r];
+    }
+    const float mean = sum * inv_c;
+    float var = 0.f;
+    for (int g = 0; g < p4; ++g) {
+      const f32x4 v = x[(int64_t)g * HW];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (g * 4 + r < p.C) {
+          const float d = v[r] - mean;
+          var += d * d;
+        }
+    }
+    const float rstd = rsqrtf(var * inv_c + p.eps);
+    for (int pl = 0; pl < planes; ++pl) {
+      float y[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int g = pl * 2 + half;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (g < p4) v = x[(int64_t)g * HW];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = g * 4 + r;
+          y[half * 4 + r] = (c < p.C) ? (v[r] - mean) * rstd * p.gamma[c] + p.beta[c] : 0.f;
+        }
+        if (p.out_f32 != nullptr && g < p4)
+          ((f32x4*)p.out_f32)[((int64_t)n * p4 + g) * HW + pix] = (f32x4){y[half * 4], y[half * 4 + 1], y[half * 4 + 2], y[half * 4 + 3]};
+      }
+      if (p.out_hi != nullptr) {
+        bf16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const __bf16 hb = (__bf16)y[j];
+          h[j] = hb;
+          l[j] = (__bf16)(y[j] - (float)hb);
+        }
+        const int64_t unit = (int64_t)n * p.out_batch_stride + (int64_t)pl * p.out_plane_stride + pix;
+        ((bf16x8*)p.out_hi)[unit] = h;
+        if (p.out_lo != nullptr) ((bf16x8*)p.out_lo)[unit] = l;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ window attention
+__device__ __forceinline__ bf16x8 pack_hi(const float (&v)[8]) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)v[j];
+  return r;
+}
+
+template <int PROD>
+__global__ __launch_bounds__(256, 2) void window_attention_kernel(const rsa_window_attn_params p) {
+  // wave-private V images: [hi|lo][64 keys][32 channels] bf16, row-major (64-byte rows)
+  __shared__ __attribute__((aligned(16))) __bf16 s_v[4][2][64 * 32];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int w = p.window;
+  const int ntok = w * w;
+  const int nwx = p.W / w, nwy = p.H / w;
+  const int64_t nwin = (int64_t)p.batch * nwy * nwx;
+  const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+  if (item >= nwin * p.heads) return;  // whole wave exits: every later instruction runs with EXEC all ones
+  const int head = (int)(item % p.heads);
+  const int64_t win = item / p.heads;
+  const int wx = (int)(win % nwx);
+  const int wy = (int)((win / nwx) % nwy);
+  const int n = (int)(win / ((int64_t)nwx * nwy));
+
+  const int lr = lane & 31;  // token column / channel row owned inside a 32-wide tile
+  const int lh = lane >> 5;  // which half of the k-group / row-group
+
+  // pixel of window token t after the cyclic shift (torch.roll(-s) then partition; the result is rolled back, so the
+  // output of token t lands on the same pixel it was read from)
+  auto token_pix = [&](int t) -> int64_t {
+    const int tt = t < ntok ? t : 0;
+    const int ty = tt / w, tx = tt - ty * w;
+    int py = wy * w + ty + p.shift;
+    int px = wx * w + tx + p.shift;
+    if (py >= p.H) py -= p.H;
+    if (px >= p.W) px -= p.W;
+    return (int64_t)py * p.W + px;
+  };
+
+  const bf16x8* qkv_hi = (const bf16x8*)p.qkv_hi + (int64_t)n * p.qkv_batch_stride;
+  const bf16x8* qkv_lo = (PROD == 3) ? (const bf16x8*)p.qkv_lo + (int64_t)n * p.qkv_batch_stride : nullptr;
+  const int64_t ps = p.qkv_plane_stride;
+  const int64_t q_plane0 = (int64_t)(0 * p.heads + head) * 4;
+  const int64_t k_plane0 = (int64_t)(1 * p.heads + head) * 4;
+  const int64_t v_plane0 = (int64_t)(2 * p.heads + head) * 4;
+
+  // ---- fragments of K (A operand) and Q (B operand): token = 32*tile + lr, channels 16*s + 8*lh .. +7 = plane 2s+lh ----
+  int64_t pix_t[2];
+  pix_t[0] = token_pix(lr);
+  pix_t[1] = token_pix(32 + lr);
+  bf16x8 kh[2][2], qh[2][2], kl[2][2], ql[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int64_t uk = (k_plane0 + 2 * s + lh) * ps + pix_t[t];
+      const int64_t uq = (q_plane0 + 2 * s + lh) * ps + pix_t[t];
+      kh[t][s] = qkv_hi[uk];
+      qh[t][s] = qkv_hi[uq];
+      if (PROD == 3) {
+        kl[t][s] = qkv_lo[uk];
+        ql[t][s] = qkv_lo[uq];
+      }
+    }
+  // ---- V image into LDS: lane = key token, 4 planes of 8 channels ----
+  {
+    const int64_t pv = token_pix(lane);
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl) {
+      const int64_t u = (v_plane0 + pl) * ps + pv;
+      *(bf16x8*)&s_v[wave][0][lane * 32 + pl * 8] = qkv_hi[u];
+      if (PROD == 3) *(bf16x8*)&s_v[wave][1][lane * 32 + pl * 8] = qkv_lo[u];
+    }
+  }
+
+  // ---- S^T[key][query] tiles ----
+  f32x16 st[2][2];  // [key tile][query tile]
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      f32x16 a;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (PROD == 3) {
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[kt][s], qh[qt][s], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[kt][s], ql[qt][s], a, 0, 0, 0);
+        }
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[kt][s], qh[qt][s], a, 0, 0, 0);
+      }
+      st[kt][qt] = a;
+    }
+
+  // ---- + relative position bias (pre-gathered in fragment order; padded keys carry -1e30) + shift mask, softmax ----
+  // accumulator element r of lane (lr, lh): key = 32*kt + (r&3) + 8*(r>>2) + 4*lh, query = 32*qt + lr
+  const bool masked = p.shift > 0 && (wy == nwy - 1 || wx == nwx - 1);
+  auto region = [&](int t) -> int {  // img_mask region id of a window token on the SHIFTED grid (arch.py:268-293)
+    const int tt = t < ntok ? t : 0;
+    const int ty = tt / w, tx = tt - ty * w;
+    const int gy = wy * w + ty, gx = wx * w + tx;
+    const int ry = gy < p.H - w ? 0 : (gy < p.H - p.shift ? 1 : 2);
+    const int rx = gx < p.W - w ? 0 : (gx < p.W - p.shift ? 1 : 2);
+    return ry * 3 + rx;
+  };
+  float inv_l[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int rq = masked ? region(32 * qt + lr) : 0;
+    float m = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const f32x4* bf = (const f32x4*)(p.bias_frag + ((((int64_t)head * 2 + qt) * 2 + kt) * 64 + lane) * 16);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b = bf[g];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = g * 4 + e;
+          float v = st[kt][qt][r] + b[e];
+          if (masked) {
+            const int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (region(key) != rq) v += -100.f;
+          }
+          st[kt][qt][r] = v;
+          m = fmaxf(m, v);
+        }
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = expf(st[kt][qt][r] - m);
+        st[kt][qt][r] = e;
+        l += e;
+      }
+    l += __shfl_xor(l, 32);
+    inv_l[qt] = 1.f / l;
+  }
+
+  // ---- O^T[channel][query] = sum_keys V^T P^T : A = V^T via transpose reads, B = P^T straight from the accumulators ----
+  f32x16 ot[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[qt][r] = 0.f;
+  const int g16 = lane >> 4;  // 16-lane group: channel half = g16&1, k-half = g16>>1 (== lh)
+  const int li16 = lane & 15;
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      // V^T fragment: element j <-> key 32kt + 16s + 8(j>>2) + 4lh + (j&3), channel lr (the k-order of the accumulator-as-operand)
+      bf16x8 vh, vl;
+#pragma unroll
+      for (int g2 = 0; g2 < 2; ++g2) {
+        const int row = 32 * kt + 16 * s + 8 * g2 + 4 * lh + (li16 >> 2);
+        const int col = 16 * (g16 & 1) + 4 * (li16 & 3);
+        const bf16x4 th = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)&s_v[wave][0][row * 32 + col]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vh[g2 * 4 + e] = th[e];
+        if (PROD == 3) {
+          const bf16x4 tl = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)&s_v[wave][1][row * 32 + col]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vl[g2 * 4 + e] = tl[e];
+        }
+      }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        float e8[8], r8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e8[j] = st[kt][qt][8 * s + j];
+        const bf16x8 ph = pack_hi(e8);
+        if (PROD == 3) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) r8[j] = e8[j] - (float)ph[j];
+          const bf16x8 pl = pack_hi(r8);
+          ot[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, ot[qt], 0, 0, 0);
+          ot[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, ot[qt], 0, 0, 0);
+        }
+        ot[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, ot[qt], 0, 0, 0);
+      }
+    }
+
+  // ---- normalise and store: lane owns token 32qt+lr, channels 8g + 4lh .. +3 (g = 0..3) ----
+  char* out_hi = (char*)p.out_hi + (int64_t)n * p.out_batch_stride * 16;
+  char* out_lo = (p.out_lo != nullptr) ? (char*)p.out_lo + (int64_t)n * p.out_batch_stride * 16 : nullptr;
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int tok = 32 * qt + lr;
+    if (tok >= ntok) continue;
+    const int64_t pix = pix_t[qt];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = ot[qt][g * 4 + e] * inv_l[qt];
+        const __bf16 hb = (__bf16)v;
+        h[e] = hb;
+        l[e] = (__bf16)(v - (float)hb);
+      }
+      const int64_t off = (((int64_t)head * 4 + g) * p.out_plane_stride + pix) * 16 + lh * 8;
+      *(bf16x4*)(out_hi + off) = h;
+      if (out_lo != nullptr) *(bf16x4*)(out_lo + off) = l;
+    }
+  }
+}
+
+}  // namespace rsa
+
+extern "C" int rsa_layernorm(const rsa_layernorm_params* p, void* stream) {
+  using namespace rsa;
+  if (p == nullptr) return set_error(RSA_E_ARG, "layernorm: null params");
+  if (p->batch < 1 || p->H < 1 || p->W < 1 || p->C < 1) return set_error(RSA_E_ARG, "layernorm: bad geometry");
+  if (!p->x_f32 || !p->gamma || !p->beta || (!p->out_hi && !p->out_f32)) return set_error(RSA_E_ARG, "layernorm: null pointer");
+  if (((uintptr_t)p->x_f32 | (uintptr_t)p->out_hi | (uintptr_t)p->out_lo | (uintptr_t)p->out_f32) & 15)
+    return set_error(RSA_E_ALIGN, "layernorm: maps must be 16-byte aligned");
+  const int64_t total = (int64_t)p->batch * p->H * p->W;
+  int64_t g = (total + 255) / 256;
+  if (g > 256 * 32) g = 256 * 32;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, *p);
+  const int rc = (int)hipGetLastError();
+  return rc ? set_error(rc, "layernorm: launch failed") : RSA_OK;
+}
+
+extern "C" int rsa_window_attention(const rsa_window_attn_params* p, void* stream) {
+  using namespace rsa;
+  if (p == nullptr) return set_error(RSA_E_ARG, "window_attention: null params");
+  if (p->batch < 1 || p->H < 1 || p->W < 1 || p->heads < 1) return set_error(RSA_E_ARG, "window_attention: bad geometry");
+  if (p->window < 1 || p->window > 8) return set_error(RSA_E_UNSUPPORTED, "window_attention: window must be 1..8 (<= 64 tokens)");
+  if (p->H % p->window || p->W % p->window) return set_error(RSA_E_ARG, "window_attention: H and W must be multiples of the window");
+  if (p->shift < 0 || p->shift >= p->window) return set_error(RSA_E_ARG, "window_attention: shift must be in [0, window)");
+  if (p->products != 1 && p->products != 3) return set_error(RSA_E_UNSUPPORTED, "window_attention: products must be 1 or 3");
+  if (!p->qkv_hi || !p->bias_frag || !p->out_hi || (p->products == 3 && !p->qkv_lo)) return set_error(RSA_E_ARG, "window_attention: null pointer");
+  if (((uintptr_t)p->qkv_hi | (uintptr_t)p->qkv_lo | (uintptr_t)p->out_hi | (uintptr_t)p->out_lo | (uintptr_t)p->bias_frag) & 15)
+    return set_error(RSA_E_ALIGN, "window_attention: pointers must be 16-byte aligned");
+  const int64_t items = (int64_t)p->batch * (p->H / p->window) * (p->W / p->window) * p->heads;
+  const int64_t blocks = (items + 3) / 4;
+  if (blocks > 0x7fffffff) return set_error(RSA_E_UNSUPPORTED, "window_attention: too many windows");
+  if (p->products == 3)
+    hipLaunchKernelGGL(window_attention_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *p);
+  else
+    hipLaunchKernelGGL(window_attention_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *p);
+  const int rc = (int)hipGetLastError();
+  return rc ? set_error(rc, "window_attention: launch failed") : RSA_OK;
+}

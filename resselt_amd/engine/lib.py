@@ -79,6 +79,49 @@ class DySampleParams(C.Structure):
     ]
 
 
+class LayerNormParams(C.Structure):
+    """Mirror of ``struct rsa_layernorm_params``."""
+
+    _fields_ = [
+        ('batch', C.c_int32),
+        ('H', C.c_int32),
+        ('W', C.c_int32),
+        ('C', C.c_int32),
+        ('eps', C.c_float),
+        ('x_f32', C.c_void_p),
+        ('gamma', C.c_void_p),
+        ('beta', C.c_void_p),
+        ('out_hi', C.c_void_p),
+        ('out_lo', C.c_void_p),
+        ('out_plane_stride', C.c_int64),
+        ('out_batch_stride', C.c_int64),
+        ('out_f32', C.c_void_p),
+    ]
+
+
+class WindowAttnParams(C.Structure):
+    """Mirror of ``struct rsa_window_attn_params``."""
+
+    _fields_ = [
+        ('batch', C.c_int32),
+        ('H', C.c_int32),
+        ('W', C.c_int32),
+        ('heads', C.c_int32),
+        ('window', C.c_int32),
+        ('shift', C.c_int32),
+        ('products', C.c_int32),
+        ('qkv_hi', C.c_void_p),
+        ('qkv_lo', C.c_void_p),
+        ('qkv_plane_stride', C.c_int64),
+        ('qkv_batch_stride', C.c_int64),
+        ('bias_frag', C.c_void_p),
+        ('out_hi', C.c_void_p),
+        ('out_lo', C.c_void_p),
+        ('out_plane_stride', C.c_int64),
+        ('out_batch_stride', C.c_int64),
+    ]
+
+
 # every symbol include/resselt_amd.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = (
     'rsa_version',
@@ -90,6 +133,8 @@ EXPORTS = (
     'rsa_nchw_to_planes',
     'rsa_planes_to_nchw',
     'rsa_dysample',
+    'rsa_layernorm',
+    'rsa_window_attention',
 )
 
 
@@ -123,7 +168,7 @@ def load() -> C.CDLL:
     lib.rsa_packed_weight_bytes.argtypes = [C.c_int32] * 4
     lib.rsa_packed_weight_bytes.restype = C.c_int64
     lib.rsa_nchw_to_planes.argtypes = [
-        C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_float,
+        C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_float,
         C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
     ]  # fmt: skip
     lib.rsa_nchw_to_planes.restype = C.c_int
@@ -133,6 +178,10 @@ def load() -> C.CDLL:
     lib.rsa_planes_to_nchw.restype = C.c_int
     lib.rsa_dysample.argtypes = [C.POINTER(DySampleParams), C.c_void_p]
     lib.rsa_dysample.restype = C.c_int
+    lib.rsa_layernorm.argtypes = [C.POINTER(LayerNormParams), C.c_void_p]
+    lib.rsa_layernorm.restype = C.c_int
+    lib.rsa_window_attention.argtypes = [C.POINTER(WindowAttnParams), C.c_void_p]
+    lib.rsa_window_attention.restype = C.c_int
     _lib = lib
     return lib
 

@@ -143,17 +143,20 @@ def run_convs(params: list[L.ConvParams], device) -> None:
 
 
 def nchw_to_planes(x: torch.Tensor, out: Planes, mean: torch.Tensor | None = None, scale: float = 1.0) -> None:
-    """Plain [N,C,H,W] tensor -> split planes on the GPU (rsa_nchw_to_planes)."""
+    """Plain [N,C,h,w] tensor -> split planes on the GPU (rsa_nchw_to_planes).
+
+    ``out`` may be larger than ``x`` (up to 2x-1): the extra rows/columns are reflect-padded (SwinIR window padding).
+    """
     require_cuda(x, 'nchw_to_planes')
     if not x.is_contiguous():
         x = x.contiguous()
     n, c, h, w = x.shape
-    if (out.n, out.h, out.w) != (n, h, w) or out.planes < (c + 7) // 8:
+    if out.n != n or out.h < h or out.w < w or out.planes < (c + 7) // 8:
         raise ValueError('output planes do not match the input tensor')
     lib = L.load()
     L.check(
         lib.rsa_nchw_to_planes(
-            x.data_ptr(), rsa_dtype(x.dtype), n, c, h, w, None if mean is None else mean.data_ptr(), scale,
+            x.data_ptr(), rsa_dtype(x.dtype), n, c, out.h, out.w, h, w, None if mean is None else mean.data_ptr(), scale,
             out.hi_ptr(), out.lo_ptr(), out.plane_stride, out.batch_stride, C.c_void_p(current_stream_ptr(x.device)),
         ),
         'rsa_nchw_to_planes',

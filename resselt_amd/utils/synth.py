@@ -129,3 +129,92 @@ def span_state_dict(num_in_ch=3, feature_channels=48, upscale=4, seed=0, norm=Tr
     if not norm:
         sd['no_norm'] = torch.zeros(1)
     return sd
+
+
+def swinir_state_dict(in_ch=3, embed_dim=60, depths=(2, 2), num_heads=(6, 6), window=8, mlp_ratio=2.0, upscale=2, upsampler='nearest+conv',
+                      resi='1conv', img_size=64, seed=0, scale=1.0):
+    """Keys of the reference SwinIR module (archs/swinir/arch.py:735-960) incl. its registered buffers.
+
+    LayerNorm weights are 1 + u, biases and the relative-position table are drawn at the same +-1/sqrt(fan_in) scale.
+    """
+    sd: OrderedDict = OrderedDict()
+    C = embed_dim
+    hidden = int(C * mlp_ratio)
+
+    def lin(name, cout, cin, bias=True):
+        sd[f'{name}.weight'] = synth_tensor(f'{name}.weight', (cout, cin), cin, seed, scale)
+        if bias:
+            sd[f'{name}.bias'] = synth_tensor(f'{name}.bias', (cout,), cin, seed, scale)
+
+    def ln(name):
+        sd[f'{name}.weight'] = 1.0 + synth_tensor(f'{name}.weight', (C,), 16, seed)
+        sd[f'{name}.bias'] = synth_tensor(f'{name}.bias', (C,), 16, seed)
+
+    def resi_conv(name):
+        if resi == '1conv':
+            _conv(sd, name, C, C, 3, seed)
+        else:
+            _conv(sd, f'{name}.0', C // 4, C, 3, seed)
+            _conv(sd, f'{name}.2', C // 4, C // 4, 1, seed)
+            _conv(sd, f'{name}.4', C, C // 4, 3, seed)
+
+    # relative_position_index buffer (arch.py:111-122)
+    ch, cw = torch.arange(window), torch.arange(window)
+    coords = torch.stack(torch.meshgrid([ch, cw], indexing='ij')).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += window - 1
+    rel[:, :, 1] += window - 1
+    rel[:, :, 0] *= 2 * window - 1
+    rp_index = rel.sum(-1)
+
+    def shift_mask():
+        H = W = img_size
+        s_ = window // 2
+        img = torch.zeros(1, H, W, 1)
+        cnt = 0
+        for hs in (slice(0, -window), slice(-window, -s_), slice(-s_, None)):
+            for ws in (slice(0, -window), slice(-window, -s_), slice(-s_, None)):
+                img[:, hs, ws, :] = cnt
+                cnt += 1
+        mw = img.view(1, H // window, window, W // window, window, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, window * window)
+        d = mw.unsqueeze(1) - mw.unsqueeze(2)
+        return torch.where(d != 0, torch.full_like(d, -100.0), torch.zeros_like(d))
+
+    _conv(sd, 'conv_first', C, in_ch, 3, seed)
+    ln('patch_embed.norm')
+    for i, depth in enumerate(depths):
+        for j in range(depth):
+            b = f'layers.{i}.residual_group.blocks.{j}'
+            if j % 2 == 1:
+                sd[f'{b}.attn_mask'] = shift_mask()
+            ln(f'{b}.norm1')
+            sd[f'{b}.attn.relative_position_bias_table'] = synth_tensor(f'{b}.rpb', ((2 * window - 1) ** 2, num_heads[i]), 4, seed)
+            sd[f'{b}.attn.relative_position_index'] = rp_index.clone()
+            lin(f'{b}.attn.qkv', 3 * C, C)
+            lin(f'{b}.attn.proj', C, C)
+            ln(f'{b}.norm2')
+            lin(f'{b}.mlp.fc1', hidden, C)
+            lin(f'{b}.mlp.fc2', C, hidden)
+        resi_conv(f'layers.{i}.conv')
+    ln('norm')
+    resi_conv('conv_after_body')
+    nf = 64
+    if upsampler == 'nearest+conv':
+        _conv(sd, 'conv_before_upsample.0', nf, C, 3, seed)
+        for u in range(1, {2: 1, 4: 2, 8: 3}[upscale] + 1):
+            _conv(sd, f'conv_up{u}', nf, nf, 3, seed)
+        _conv(sd, 'conv_hr', nf, nf, 3, seed)
+        _conv(sd, 'conv_last', in_ch, nf, 3, seed)
+    elif upsampler == 'pixelshuffle':
+        _conv(sd, 'conv_before_upsample.0', nf, C, 3, seed)
+        if upscale == 3:
+            _conv(sd, 'upsample.0', 9 * nf, nf, 3, seed)
+        else:
+            for u in range({2: 1, 4: 2, 8: 3}[upscale]):
+                _conv(sd, f'upsample.{2 * u}', 4 * nf, nf, 3, seed)
+        _conv(sd, 'conv_last', in_ch, nf, 3, seed)
+    elif upsampler == 'pixelshuffledirect':
+        _conv(sd, 'upsample.0', upscale * upscale * in_ch, C, 3, seed)
+    else:
+        _conv(sd, 'conv_last', in_ch, C, 3, seed)
+    return sd

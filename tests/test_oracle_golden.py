@@ -9,7 +9,7 @@ import torch
 
 from helpers import golden_names, load_golden, oracle_forward, synth_state_dict
 
-E2E = golden_names('rrdbnet_') + golden_names('spanplus_') + golden_names('span_')
+E2E = golden_names('rrdbnet_') + golden_names('spanplus_') + golden_names('span_') + golden_names('swinir_')
 
 
 @pytest.mark.parametrize('name', E2E)
@@ -51,3 +51,14 @@ def test_oracle_span_blocks():
     out, out1 = spab(sd, 'feats.1.block_1', arr['x'], F.mish)
     assert (out - arr['spab_out']).abs().max() <= 1e-5
     assert (out1 - arr['spab_out1']).abs().max() <= 1e-5
+
+
+def test_oracle_swin_blocks():
+    from oracle.swinir import swin_block
+
+    meta, arr = load_golden('blocks_swin')
+    sd = synth_state_dict(meta)
+    t = arr['x']
+    for j, shift in ((0, 0), (1, 4)):
+        t = swin_block(sd, f'layers.0.residual_group.blocks.{j}', t, 16, 24, 8, shift, 8)
+        assert (t - arr[f'block{j}']).abs().max() <= 2e-5, j
