@@ -5,10 +5,11 @@ Contract (see the task statement): ``python bench.py --gpus N --steps K --warmup
 A *step* is one full forward pass of the hot path over one synthetic 3x1080x1920 frame per GPU
 (1920x1080 -> 7680x4320 = 33.18 output MP), input resident in HBM before the timed region, output left in HBM.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): tile-parallel inference of ONE image that is N
-frames tall: every rank upsamples its own 1080p tile (weak scaling, no activation exchange -- the path shards
-by independent tiles) and the upscaled tiles are reassembled on every rank by an RCCL
-all-gather over xGMI, which is inside the timed region.  ``value`` = all ranks' output MP / max-over-ranks time.
+N > 1 (launched by torch.distributed.run, one rank per GPU): tile-parallel inference (resselt_amd/tiling.py) of ONE
+image made of N 1080p tiles (grid chosen by choose_grid: 1x2, 2x2, 2x4): every rank upsamples its own tile plus a
+32-pixel input halo (weak scaling; no activation exchange -- the path shards by independent tiles) and
+the upscaled tiles are reassembled on every rank by an RCCL all-gather over xGMI, which is inside the timed region.
+``value`` = output MP of the whole image / max-over-ranks time.
 
 Extra objects on the JSON line:
   roofline      dominant kernel (the fused conv kernel family = every launch of the forward), MFMA-bound:
@@ -49,6 +50,7 @@ def parse():
     ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-crop', type=int, default=256)
+    ap.add_argument('--halo', type=int, default=32)
     return ap.parse_args()
 
 
@@ -102,17 +104,15 @@ def main():
     model = resselt_amd.load_from_state_dict(dict(sd)).to(dev)
     model.precision = args.precision
     H, W = args.height, args.width
-    # each rank owns one HxW tile of an image that is `world` tiles tall (seeded per rank)
-    x = synth.synth_input((1, 3, H, W), seed=rank).to(dev)
-    gathered = None
-    if world > 1:
-        gathered = torch.empty((world, 3, 4 * H, 4 * W), dtype=torch.float32, device=dev)
+    from resselt_amd.tiling import TileParallel, choose_grid
+
+    rows, cols = choose_grid(world, world * H, W) if world > 1 else (1, 1)
+    # the same full input image on every rank (3 channels: cheap to replicate); each rank owns one HxW tile of it
+    x = synth.synth_input((1, 3, rows * H, cols * W), seed=0).to(dev)
+    runner = TileParallel(model, scale=4, halo=args.halo, grid=(rows, cols)) if world > 1 else model
 
     def step():
-        y = model(x)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, y)  # RCCL over xGMI: every rank ends with the whole image
-        return y
+        return runner(x)  # N > 1: tile forward + RCCL all-gather; every rank ends with the whole upscaled image
 
     for _ in range(args.warmup):
         step()
@@ -140,19 +140,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    out_px = y.shape[-1] * y.shape[-2] * y.shape[0]
+    total_out_px = y.shape[-1] * y.shape[-2] * y.shape[0]  # whole image (on every rank after the all-gather)
+    out_px = total_out_px // world  # one tile
     ms_per_step = dt / args.steps * 1e3
-    value = world * out_px / 1e6 / (dt / args.steps)
+    value = total_out_px / 1e6 / (dt / args.steps)
 
     if rank == 0:
         # kernel-only time of the conv launches of one forward, from HIP events on the launch stream
         k0 = torch.cuda.Event(enable_timing=True)
         k1 = torch.cuda.Event(enable_timing=True)
-        model(x)
+        xt = x[:, :, :H, :W].contiguous()
+        model(xt)
         torch.cuda.synchronize()
         k0.record()
         for _ in range(args.steps):
-            model(x)
+            model(xt)
         k1.record()
         torch.cuda.synchronize()
         kern_s = k0.elapsed_time(k1) / 1e3 / args.steps
@@ -181,7 +183,7 @@ def main():
                 + ('bf16 MFMA operands split hi+lo (3 products), f32 accumulate/residual' if args.precision == 'bf16x3' else 'plain bf16 MFMA operands, f32 accumulate/residual')
                 + ', synthetic uniform(+-1/sqrt(fan_in)) weights',
                 'precision': args.precision,
-                'tile_parallel': f'{world} tile(s) of {H}x{W}, RCCL all-gather of fp32 outputs' if world > 1 else 'single tile',
+                'tile_parallel': f'{rows}x{cols} tiles of {H}x{W} (+{args.halo} px input halo), one per GPU, RCCL all-gather of fp32 output tiles' if world > 1 else 'single tile',
                 'launches_per_step': n_launch,
             },
             'roofline': {

@@ -1,0 +1,166 @@
+"""Tile-parallel whole-image inference.
+
+The reference has no tiler and no distributed code; every SR model in scope is translation-equivariant up to its
+receptive field, so an image shards into independent *input* tiles (3 channels: tiny) that are widened by a halo,
+upscaled independently and cropped.  No activation ever crosses a GPU boundary; the only collective is the final
+reassembly: an all-gather of equal-sized (padded) output tiles over RCCL/xGMI (``torch.distributed`` backend "nccl"
+on ROCm), after which every rank holds the whole upscaled image.
+
+Host logic only: works with any callable ``model(x) -> y`` (the CPU tests drive it with the oracle over gloo).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Sequence
+
+import torch
+
+
+@dataclass(frozen=True)
+class Tile:
+    """One work item in input-pixel coordinates. ``y0:y1, x0:x1`` is the region this tile OWNS in the output grid;
+    ``ry0:ry1, rx0:rx1`` is what it reads (owned region + halo, clamped to the image)."""
+
+    index: int
+    y0: int
+    y1: int
+    x0: int
+    x1: int
+    ry0: int
+    ry1: int
+    rx0: int
+    rx1: int
+
+    @property
+    def shape(self) -> tuple[int, int]:
+        return self.y1 - self.y0, self.x1 - self.x0
+
+
+def _splits(total: int, parts: int, align: int) -> list[int]:
+    """Boundaries of `parts` near-equal chunks of [0, total), interior boundaries rounded to `align`."""
+    edges = [0]
+    for i in range(1, parts):
+        e = round(total * i / parts / align) * align
+        edges.append(min(max(e, edges[-1]), total))
+    edges.append(total)
+    return edges
+
+
+def choose_grid(n_tiles: int, height: int, width: int) -> tuple[int, int]:
+    """rows x cols = n_tiles with tile aspect closest to square (e.g. 8 tiles of a 16:9 frame -> 2 x 4)."""
+    best = None
+    for rows in range(1, n_tiles + 1):
+        if n_tiles % rows:
+            continue
+        cols = n_tiles // rows
+        th, tw = height / rows, width / cols
+        score = max(th / tw, tw / th)
+        if best is None or score < best[0]:
+            best = (score, rows, cols)
+    return best[1], best[2]
+
+
+def plan_tiles(height: int, width: int, rows: int, cols: int, halo: int = 32, align: int = 1) -> list[Tile]:
+    """Partition an H x W input into rows x cols tiles.  ``align`` keeps interior tile edges AND halo-extended read
+    windows on multiples of e.g. the SwinIR window, so window partitions of a tile coincide with the full frame's."""
+    if rows < 1 or cols < 1 or halo < 0 or align < 1:
+        raise ValueError('rows, cols >= 1, halo >= 0, align >= 1 required')
+    if halo % align:
+        halo = (halo // align + 1) * align
+    ys, xs = _splits(height, rows, align), _splits(width, cols, align)
+    tiles = []
+    for r in range(rows):
+        for c in range(cols):
+            y0, y1, x0, x1 = ys[r], ys[r + 1], xs[c], xs[c + 1]
+            tiles.append(Tile(len(tiles), y0, y1, x0, x1, max(y0 - halo, 0), min(y1 + halo, height), max(x0 - halo, 0), min(x1 + halo, width)))
+    return tiles
+
+
+def run_tile(model: Callable[[torch.Tensor], torch.Tensor], x: torch.Tensor, tile: Tile, scale: int) -> torch.Tensor:
+    """Upscale one tile (with its halo) and crop the halo off the result."""
+    if tile.y1 <= tile.y0 or tile.x1 <= tile.x0:
+        return x.new_zeros((x.shape[0], 0, 0, 0))
+    crop = x[:, :, tile.ry0 : tile.ry1, tile.rx0 : tile.rx1].contiguous()
+    y = model(crop)
+    oy, ox = (tile.y0 - tile.ry0) * scale, (tile.x0 - tile.rx0) * scale
+    th, tw = tile.shape
+    return y[:, :, oy : oy + th * scale, ox : ox + tw * scale]
+
+
+def upscale_tiled(model, x: torch.Tensor, scale: int, tile: tuple[int, int], halo: int = 32, align: int = 1) -> torch.Tensor:
+    """Single-device tiling of a large image: bounds the engine's activation buffers (e.g. 8K inputs)."""
+    n, _, h, w = x.shape
+    rows, cols = -(-h // tile[0]), -(-w // tile[1])
+    out = None
+    for t in plan_tiles(h, w, rows, cols, halo, align):
+        y = run_tile(model, x, t, scale)
+        if out is None:
+            out = torch.empty((n, y.shape[1], h * scale, w * scale), dtype=y.dtype, device=y.device)
+        out[:, :, t.y0 * scale : t.y1 * scale, t.x0 * scale : t.x1 * scale] = y
+    return out
+
+
+class TileParallel:
+    """``TileParallel(model, scale)(x)``: every rank of the process group upscales its share of the tiles of ``x`` and
+    all ranks return the complete upscaled image.
+
+    ``x`` must be the same full input on every rank (a 3-channel image is cheap to replicate; only the outputs and
+    the activations are large).  With ``world_size`` ranks the image is cut into ``world_size`` tiles (one per rank)
+    unless ``grid`` says otherwise; tiles are assigned round-robin.
+    """
+
+    def __init__(self, model: Callable[[torch.Tensor], torch.Tensor], scale: int, halo: int = 32, align: int = 1,
+                 grid: tuple[int, int] | None = None, group=None):  # fmt: skip
+        self.model, self.scale, self.halo, self.align, self.grid, self.group = model, scale, halo, align, grid, group
+
+    def tiles_for(self, height: int, width: int, world: int) -> list[Tile]:
+        rows, cols = self.grid if self.grid is not None else choose_grid(world, height, width)
+        return plan_tiles(height, width, rows, cols, self.halo, self.align)
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()):
+            world, rank = 1, 0
+        else:
+            world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        n, _, h, w = x.shape
+        s = self.scale
+        tiles = self.tiles_for(h, w, world)
+        mine = tiles[rank::world]
+        outs = [run_tile(self.model, x, t, s) for t in mine]
+        ref = next((o for o in outs if o.numel()), None)
+        if world == 1:
+            full = torch.empty((n, ref.shape[1], h * s, w * s), dtype=ref.dtype, device=ref.device)
+            for t, o in zip(mine, outs):
+                full[:, :, t.y0 * s : t.y1 * s, t.x0 * s : t.x1 * s] = o
+            return full
+        # equal-sized slots so that ONE all-gather moves everything: pad each tile to the largest tile
+        mh = max(t.shape[0] for t in tiles) * s
+        mw = max(t.shape[1] for t in tiles) * s
+        per_rank = -(-len(tiles) // world)
+        c_out, dtype, device = self._out_meta(ref, x, outs)
+        send = torch.zeros((per_rank, n, c_out, mh, mw), dtype=dtype, device=device)
+        for k, (t, o) in enumerate(zip(mine, outs)):
+            if o.numel():
+                send[k, :, :, : o.shape[2], : o.shape[3]] = o
+        recv = torch.empty((world * per_rank, n, c_out, mh, mw), dtype=dtype, device=device)
+        dist.all_gather_into_tensor(recv, send, group=self.group)  # output = concatenation of the ranks' slots along dim 0
+        recv = recv.view(world, per_rank, n, c_out, mh, mw)
+        full = torch.empty((n, c_out, h * s, w * s), dtype=dtype, device=device)
+        for t in tiles:
+            r, k = t.index % world, t.index // world
+            th, tw = t.shape
+            full[:, :, t.y0 * s : t.y1 * s, t.x0 * s : t.x1 * s] = recv[r, k, :, :, : th * s, : tw * s]
+        return full
+
+    def _out_meta(self, ref, x, outs):
+        import torch.distributed as dist
+
+        if ref is not None:
+            return ref.shape[1], ref.dtype, ref.device
+        # a rank without work still has to join the collective with the right shape: ask rank 0
+        meta = [None]
+        dist.broadcast_object_list(meta, src=0, group=self.group)
+        return meta[0]

@@ -101,3 +101,17 @@ def test_rrdbnet_full_frame_tile_consistency(device):
     # image borders use zero padding exactly like the reference: top-left corner equals a corner crop
     corner = m(x[:, :, : s + halo, : s + halo].contiguous())
     assert (y[:, :, : 4 * s, : 4 * s] - corner[:, :, : 4 * s, : 4 * s]).abs().max().item() <= 1e-4
+
+
+def test_rrdbnet_tiled_driver_on_gpu(device):
+    """resselt_amd.tiling over the real engine: sequential tiles with halo reproduce the full frame."""
+    from resselt_amd.tiling import TileParallel, upscale_tiled
+
+    sd = synth.rrdbnet_state_dict(nb=23, seed=1)
+    m = _model(sd, device)
+    x = synth.synth_input((1, 3, 150, 210), seed=1).to(device)
+    full = m(x)
+    tiled = upscale_tiled(m, x, scale=4, tile=(80, 112), halo=40)
+    assert tiled.shape == full.shape and (tiled - full).abs().max().item() <= 1e-4
+    one = TileParallel(m, scale=4, halo=40, grid=(2, 2))(x)  # world size 1: all four tiles on this GPU
+    assert (one - full).abs().max().item() <= 1e-4

@@ -1,0 +1,97 @@
+"""Tile-parallel driver (resselt_amd/tiling.py): planning logic, single-process tiling and the world_size-2 path over
+gloo on CPU with the oracle as the per-tile model (the GPU engine is not involved here)."""
+
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from resselt_amd.tiling import TileParallel, choose_grid, plan_tiles, upscale_tiled
+from resselt_amd.utils import synth
+
+
+def _model():
+    from oracle.rrdbnet import rrdbnet_forward
+
+    sd = synth.rrdbnet_state_dict(nb=1, nf=16, scale=2, seed=4)
+
+    def run(x):
+        with torch.no_grad():
+            return rrdbnet_forward(sd, x)
+
+    return run
+
+
+def test_grid_and_plan_cover_the_image_exactly():
+    assert choose_grid(8, 4320, 7680) == (2, 4) and choose_grid(4, 1080, 1920) == (2, 2) and choose_grid(1, 10, 10) == (1, 1)
+    assert choose_grid(2, 1080, 1920) == (1, 2) and choose_grid(3, 100, 100) in ((1, 3), (3, 1))
+    for (h, w, r, c, halo, align) in [(4320, 7680, 2, 4, 32, 1), (50, 70, 3, 2, 8, 8), (17, 5, 4, 1, 3, 1), (64, 64, 2, 2, 12, 8)]:
+        tiles = plan_tiles(h, w, r, c, halo, align)
+        cover = torch.zeros(h, w, dtype=torch.int32)
+        for t in tiles:
+            cover[t.y0 : t.y1, t.x0 : t.x1] += 1
+            assert t.ry0 <= t.y0 <= t.y1 <= t.ry1 <= h and t.rx0 <= t.x0 <= t.x1 <= t.rx1 <= w
+            assert t.ry0 in (0, max(t.y0 - (halo if halo % align == 0 else (halo // align + 1) * align), 0))
+            if align > 1:  # interior edges and read windows stay on the alignment grid
+                assert t.y0 % align == 0 and t.x0 % align == 0 and t.ry0 % align == 0 and t.rx0 % align == 0
+        assert int(cover.min()) == 1 and int(cover.max()) == 1
+    with pytest.raises(ValueError):
+        plan_tiles(10, 10, 0, 1)
+
+
+def test_single_process_tiling_matches_full_frame():
+    model = _model()
+    x = synth.synth_input((1, 3, 45, 61), seed=8)
+    full = model(x)
+    # halo 24 exceeds the receptive-field radius of this 1-block net (18 LR px): tiles agree to fp32 rounding
+    tiled = upscale_tiled(model, x, scale=2, tile=(20, 32), halo=24)
+    assert tiled.shape == full.shape and (tiled - full).abs().max().item() <= 1e-6
+    # without halo the seams differ (this is what the halo is for)
+    assert (upscale_tiled(model, x, scale=2, tile=(20, 32), halo=0) - full).abs().max().item() > 1e-4
+    # world_size 1 TileParallel is the same computation
+    assert torch.equal(TileParallel(model, 2, halo=24, grid=(2, 2))(x), upscale_tiled(model, x, scale=2, tile=(23, 31), halo=24))
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        model = _model()
+        x = synth.synth_input((1, 3, 40, 52), seed=9)  # every rank builds the same input
+        y = TileParallel(model, scale=2, halo=24)(x)
+        y3 = TileParallel(model, scale=2, halo=24, grid=(3, 1))(x)  # 3 uneven tiles on 2 ranks: round-robin + padding
+        q.put((rank, y, y3))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_tile_parallel_all_gather_gloo():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict()
+    for _ in range(2):
+        rank, y, y3 = q.get(timeout=120)
+        results[rank] = (y.clone(), y3.clone())
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    model = _model()
+    full = model(synth.synth_input((1, 3, 40, 52), seed=9))
+    for rank in (0, 1):
+        y, y3 = results[rank]
+        assert y.shape == full.shape
+        assert (y - full).abs().max().item() <= 1e-6, rank  # every rank ends with the whole image
+        assert (y3 - full).abs().max().item() <= 1e-6, rank
