@@ -25,289 +25,111 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "resselt_amd.h"
-#include "common.h"
+#include "conv_common.h"
 
 namespace rsa {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-
-constexpr int NPL = 4;  // planes per K chunk (32 channels = one MFMA K)
-constexpr int NTHREADS = 256;
-
-__device__ __forceinline__ float act_apply(float v, int act, float prm) {
-  switch (act) {
-    case RSA_ACT_LRELU:
-      return v >= 0.f ? v : v * prm;
-    case RSA_ACT_MISH: {
-      // torch: x * tanh(softplus(x)), softplus threshold 20
-      float sp = v > 20.f ? v : log1pf(expf(v));
-      return v * tanhf(sp);
-    }
-    case RSA_ACT_SILU:
-      return v / (1.f + expf(-v));
-    case RSA_ACT_GELU:
-      return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-    default:
-      return v;
-  }
-}
-
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-
-// (a, b) -> packed bf16 pair (RNE) and the pair's rounding residuals, also packed
-__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
-  const bf16x2 h = {(__bf16)a, (__bf16)b};
-  hi = __builtin_bit_cast(uint32_t, h);
-  const float ra = a - __builtin_bit_cast(float, hi << 16);
-  const float rb = b - __builtin_bit_cast(float, hi & 0xffff0000u);
-  const bf16x2 l = {(__bf16)ra, (__bf16)rb};
-  lo = __builtin_bit_cast(uint32_t, l);
-}
-
-// Geometry of one instantiation.  A workgroup is always 4 waves; a wave always owns 8 pixel-tiles (4 rows x 2 halves
-// of 16 pixels) x CTW cout-tiles, so that one tap costs it 16 LDS fragment reads + 4 weight fragment loads for up to
-// 48 MFMAs.  NCT >= 3: tile 8x32, waves = 2 cout-pairs x 2 row-groups.  NCT <= 2: tile 16x32, waves = 4 row-groups.
-template <int KS, int NCT>
-struct Geo {
-  static constexpr int WCT = (NCT >= 3) ? 2 : 1;       // waves along cout
-  static constexpr int WPX = 4 / WCT;                  // waves along rows
-  static constexpr int CTW = (NCT >= 2) ? 2 : 1;       // cout tiles per wave
-  static constexpr int TH = 4 * WPX;                   // 8 or 16 output rows
-  static constexpr int TW = 32;
-  static constexpr int HALO = KS / 2;
-  static constexpr int IH = TH + 2 * HALO;
-  static constexpr int IW = TW + 2 * HALO;
-  static constexpr int PS = ((IH * IW + 15) / 16) * 16;  // plane stride in units, == 0 mod 16
-};
-
-// Epilogue of one finished tile.  Every address is  (uniform 64-bit base) + (32-bit per-lane byte offset):
-//   lane (li, lg) of wave (wct, wpx) owns, for pixel-tile pt and cout-tile c, the 4 consecutive channels
-//   c0 = 16*(slab*NCT + 2*wct + c) + 4*lg .. +3  of pixel (y0 + 4*wpx + (pt>>1), x0 + 16*(pt&1) + li).
-// OUTK = 0: split planes and/or f32 residual map (with activation / residual epilogues)
-// OUTK = 1: final plain NCHW tensor (optional activation, depth-to-space and affine), any dtype
-template <int NCT, int CTW, int OUTK>
-__device__ __forceinline__ void epilogue(const rsa_conv_params& p, const f32x4 (&acc)[8][CTW], int n, int y0, int x0, int slab, int wct, int wpx,
-                                         int li, int lg) {
-  const int64_t HW = (int64_t)p.H * p.W;
-  const int64_t pix0 = (int64_t)y0 * p.W + x0;  // uniform
-  const int p4 = (p.cout + 3) >> 2;
-  const int cout8 = (p.cout + 7) & ~7;
-  const int ctile0 = slab * NCT + wct * 2;
-
-  uint32_t lpix[8];
-  bool pvalid[8];
-#pragma unroll
-  for (int pt = 0; pt < 8; ++pt) {
-    const int ry = wpx * 4 + (pt >> 1), rx = (pt & 1) * 16 + li;
-    lpix[pt] = (uint32_t)(ry * p.W + rx);
-    pvalid[pt] = (y0 + ry < p.H) && (x0 + rx < p.W);
-  }
-
-#pragma unroll
-  for (int ct = 0; ct < CTW; ++ct) {
-    if (wct * 2 + ct >= NCT) break;
-    const int cbase = (ctile0 + ct) * 16;  // uniform
-    if (cbase >= cout8) break;
-    const int c0 = cbase + lg * 4;
-    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr) bias = ((const f32x4*)p.bias)[c0 >> 2];  // bias is padded to a multiple of 16
-    const bool cvalid = c0 < cout8;
-    const bool has_f32grp = c0 < (p4 << 2);
-    // uniform bases for this cout tile
-    const char* r1b = (const char*)p.res1 + (((int64_t)n * p4 + (cbase >> 2)) * HW + pix0) * 16;
-    const char* r2b = (const char*)p.res2 + (((int64_t)n * p4 + (cbase >> 2)) * HW + pix0) * 16;
-    char* f32b = (char*)p.out_f32 + (((int64_t)n * p4 + (cbase >> 2)) * HW + pix0) * 16;
-    const int64_t ounit0 = (int64_t)n * p.out_batch_stride + (int64_t)(p.out_plane_off + (cbase >> 3)) * p.out_plane_stride + pix0;
-    char* ohb = (char*)p.out_hi + ounit0 * 16;
-    char* olb = (char*)p.out_lo + ounit0 * 16;
-    const uint32_t f32lane = (uint32_t)lg * (uint32_t)HW;                       // + lpix, in float4 units
-    const uint32_t pllane = (uint32_t)(lg >> 1) * (uint32_t)p.out_plane_stride;  // + lpix, in 16-byte units
-#pragma unroll
-    for (int pt = 0; pt < 8; ++pt) {
-      if (!pvalid[pt] || !cvalid) continue;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[pt][ct][r] + bias[r];
-      if (OUTK == 0) {
-        const uint32_t foff = (f32lane + lpix[pt]) * 16u;
-        if (p.act == RSA_ACT_SPAB_GATE) {
-          f32x4 rr = {0.f, 0.f, 0.f, 0.f};
-          if (has_f32grp) rr = *(const f32x4*)(r1b + foff);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float sg = 1.f / (1.f + expf(-v[r]));
-            v[r] = (v[r] + rr[r]) * (sg - 0.5f);
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act, p.act_param);
-          if (p.res1 != nullptr && has_f32grp) {
-            const f32x4 rr = *(const f32x4*)(r1b + foff);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + rr[r];
-          }
-        }
-        if (p.res2 != nullptr && has_f32grp) {
-          const f32x4 rr = *(const f32x4*)(r2b + foff);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = v[r] * p.beta + rr[r];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (c0 + r >= p.cout) v[r] = 0.f;
-        if (p.out_hi != nullptr) {
-          uint32_t h0, l0, h1, l1;
-          split2(v[0], v[1], h0, l0);
-          split2(v[2], v[3], h1, l1);
-          const uint32_t uoff = (pllane + lpix[pt]) * 16u + (uint32_t)(lg & 1) * 8u;
-          *(uint2*)(ohb + uoff) = make_uint2(h0, h1);
-          if (p.out_lo != nullptr) *(uint2*)(olb + uoff) = make_uint2(l0, l1);
-        }
-        if (p.out_f32 != nullptr && has_f32grp) *(f32x4*)(f32b + foff) = (f32x4){v[0], v[1], v[2], v[3]};
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act, p.act_param);
-        const int ps = p.pixel_shuffle > 1 ? p.pixel_shuffle : 1;
-        const int oc_total = p.cout / (ps * ps);
-        const int64_t oW = (int64_t)p.W * ps;
-        const int64_t oHW = (int64_t)p.H * ps * oW;
-        const int y = y0 + wpx * 4 + (pt >> 1), x = x0 + (pt & 1) * 16 + li;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = c0 + r;
-          if (c >= p.cout) continue;
-          const int oc = c / (ps * ps);
-          const int rem = c - oc * ps * ps;
-          const int ii = rem / ps;
-          const int jj = rem - ii * ps;
-          float o = v[r] * p.out_scale;
-          if (p.out_shift != nullptr) o += p.out_shift[oc];
-          const int64_t idx = ((int64_t)n * oc_total + oc) * oHW + ((int64_t)y * ps + ii) * oW + ((int64_t)x * ps + jj);
-          if (p.out_dtype == RSA_F32)
-            ((float*)p.out_nchw)[idx] = o;
-          else if (p.out_dtype == RSA_F16)
-            ((_Float16*)p.out_nchw)[idx] = (_Float16)o;
-          else
-            ((__bf16*)p.out_nchw)[idx] = (__bf16)o;
-        }
-      }
-    }
-  }
-}
+__device__ uint4 g_zero_unit[4];  // source of zero-padding units for the loader's LDS-DMA (never written)
 
 template <int KS, int NCT, int PROD, int UP, int OUTK>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_kernel(const rsa_conv_params p) {
-  using G = Geo<KS, NCT>;
+__global__ __launch_bounds__((GeoLW<KS, NCT>::NTHR), (GeoLW<KS, NCT>::NCW == 8 ? 3 : 2)) void conv_kernel(const rsa_conv_params p) {
+  using G = GeoLW<KS, NCT>;
   constexpr int TH = G::TH, TW = G::TW, HALO = G::HALO, IH = G::IH, IW = G::IW, PS = G::PS;
-  constexpr int WPX = G::WPX, CTW = G::CTW;
+  constexpr int WPX = G::WPX, CTW = G::CTW, NCW = G::NCW;
   constexpr int ACT_UNITS = NPL * PS;
   constexpr int NHL = (PROD == 3) ? 2 : 1;
-  constexpr int FILL_IT = (ACT_UNITS + NTHREADS - 1) / NTHREADS;
+  constexpr int DMA_IT = (ACT_UNITS + 63) / 64;  // LDS-DMA instructions (1 KiB each) per precision per chunk
   constexpr int T = KS * KS;
 
-  __shared__ uint4 s_act[NHL * ACT_UNITS];
+  // double-buffered halo tile: [buffer][hi|lo][plane 0..3][IH][IW] 16-byte units
+  __shared__ uint4 s_act[2][NHL * ACT_UNITS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wct = wave / WPX;  // which cout pair
-  const int wpx = wave - wct * WPX;  // which group of 4 rows
-  const int li = lane & 15;
-  const int lg = lane >> 4;
 
   const int tiles_x = (p.W + TW - 1) / TW;
   const int tiles_y = (p.H + TH - 1) / TH;
   const int tiles_img = tiles_x * tiles_y;
   const int num_tiles = tiles_img * p.batch;
   const int slab = blockIdx.y;
-
   const int inW = UP ? (p.W >> 1) : p.W;
-
   const int nchunks = (p.cin_planes + NPL - 1) / NPL;
   const int nsteps = nchunks * T;
   const int ct_total = (p.cout + 15) >> 4;
 
-  // ---- per-thread halo-fill map of the tile being FETCHED (recomputed when the prefetch moves to a new tile).
-  //      foff = BYTE offset from the chunk's first plane, or 0xFFFFFFFF for zero padding: the fetch is a raw buffer
-  //      load whose descriptor covers exactly the chunk's valid planes, so padding pixels AND missing planes come
-  //      back as zeros from the hardware range check -- no branch, no select, loads stay in flight (counted vmcnt). ----
-  uint32_t foff[FILL_IT];
-  // tile-independent part of the map, packed so that it costs ONE register per fill iteration:
-  //   bits 0-1 plane in chunk, bits 2-7 row in halo tile, bits 8-13 column, bit 16 = slot is part of the halo tile
-  uint32_t fpk[FILL_IT];
+  if ((int)blockIdx.x >= num_tiles) return;  // whole workgroup
+
+  if (wave == NCW) {
+    // =========================== LOADER WAVE ===========================
+    // Streams item (tile, q) into buffer (k & 1) while the compute waves multiply item k-1 out of the other buffer.
+    // It owns its own vmcnt stream, so a halo tile stays in flight for a whole chunk of MFMA work (the compute
+    // waves' per-tap weight waits cannot drain it).  LDS destination of one DMA instruction = base + lane*16, which
+    // is exactly 64 consecutive units of the tile image; the per-lane SOURCE address does the halo gather, the
+    // nearest-x2 read and the zero padding (invalid lanes read a zero unit).
+    const uint32_t plane_units = (uint32_t)p.in_plane_stride;
+    int k = 0;
+    for (int tile = blockIdx.x; tile < num_tiles; tile += (int)gridDim.x) {
+      const int n = tile / tiles_img;
+      const int tr = tile - n * tiles_img;
+      const int ty = tr / tiles_x;
+      const int tx = tr - ty * tiles_x;
+      const int y0 = ty * TH - HALO, x0 = tx * TW - HALO;
+      const uint4* img_hi = (const uint4*)p.in_hi + (int64_t)n * p.in_batch_stride;
+      const uint4* img_lo = (PROD == 3) ? (const uint4*)p.in_lo + (int64_t)n * p.in_batch_stride : nullptr;
+      // per-lane source map of this tile, identical for all its chunks: unit offset from the chunk's first plane,
+      // 0xFFFFFFFF = zero padding; bits 30-31 of a valid entry would overflow only for > 2^30-unit planes (rejected on the host)
+      uint32_t doff[DMA_IT];
 #pragma unroll
-  for (int it = 0; it < FILL_IT; ++it) {
-    const int u = it * NTHREADS + tid;
-    const int pl = u / PS;
-    const int r = u - pl * PS;
-    const int py = r / IW;
-    const int px = r - py * IW;
-    fpk[it] = (uint32_t)pl | ((uint32_t)py << 2) | ((uint32_t)px << 8) | ((u < ACT_UNITS && r < IH * IW) ? 0x10000u : 0u);
-    asm volatile("" : "+v"(fpk[it]));  // keep it packed: do not let the compiler hoist the unpacked fields as loop invariants
+      for (int it = 0; it < DMA_IT; ++it) {
+        const int u = it * 64 + lane;
+        const int pl = u / PS;
+        const int r = u - pl * PS;
+        const int py = r / IW;
+        const int px = r - py * IW;
+        int iy = y0 + py, ix = x0 + px;
+        const bool ok = (r < IH * IW) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        if (UP) {
+          iy >>= 1;
+          ix >>= 1;
+        }
+        doff[it] = ok ? (uint32_t)pl * plane_units + (uint32_t)iy * (uint32_t)inW + (uint32_t)ix : 0xFFFFFFFFu;
+      }
+      for (int q = 0; q < nchunks; ++q, ++k) {
+#ifdef RSA_ABL_NOBAR
+        continue;
+#endif
+#ifdef RSA_ABL_NODMA
+        if (k > 1) { __syncthreads(); continue; }
+#endif
+        const int planes_left = p.cin_planes - q * NPL;
+        const uint4* ch = img_hi + (int64_t)q * NPL * p.in_plane_stride;
+        const uint4* cl = (PROD == 3) ? img_lo + (int64_t)q * NPL * p.in_plane_stride : nullptr;
+        uint4* dst = &s_act[k & 1][0];
+#pragma unroll
+        for (int it = 0; it < DMA_IT; ++it) {
+          const int pl = (it * 64 + lane) / PS;
+          const bool ok = doff[it] != 0xFFFFFFFFu && pl < planes_left;
+          const uint4* sh = ok ? ch + doff[it] : (const uint4*)&g_zero_unit[0];
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sh,
+                                           (__attribute__((address_space(3))) void*)(dst + it * 64), 16, 0, 0);
+          if (PROD == 3) {
+            const uint4* sl = ok ? cl + doff[it] : (const uint4*)&g_zero_unit[0];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sl,
+                                             (__attribute__((address_space(3))) void*)(dst + ACT_UNITS + it * 64), 16, 0, 0);
+          }
+        }
+        __syncthreads();  // drains this wave's DMA (vmcnt(0)) and meets the compute waves: buffer (k & 1) is ready
+      }
+    }
+    return;
   }
-  const char* f_hi = nullptr;  // image base of the tile being fetched
-  const char* f_lo = nullptr;
-  const uint32_t plane_bytes = (uint32_t)p.in_plane_stride * 16u;
-  auto set_fill_tile = [&](int tile) {
-    const int n = tile / tiles_img;
-    const int tr = tile - n * tiles_img;
-    const int ty = tr / tiles_x;
-    const int tx = tr - ty * tiles_x;
-    const int y0 = ty * TH, x0 = tx * TW;
-    f_hi = (const char*)p.in_hi + (int64_t)n * p.in_batch_stride * 16;
-    if (PROD == 3) f_lo = (const char*)p.in_lo + (int64_t)n * p.in_batch_stride * 16;
-#pragma unroll
-    for (int it = 0; it < FILL_IT; ++it) {
-      const uint32_t k = fpk[it];
-      int iy = y0 - HALO + (int)((k >> 2) & 63u);
-      int ix = x0 - HALO + (int)((k >> 8) & 63u);
-      const bool ok = (k & 0x10000u) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      if (UP) {
-        iy >>= 1;
-        ix >>= 1;
-      }
-      foff[it] = ok ? ((k & 3u) * plane_bytes + ((uint32_t)iy * (uint32_t)inW + (uint32_t)ix) * 16u) : 0xFFFFFFFFu;
-    }
-  };
 
-  uint4 st_hi[FILL_IT];
-  uint4 st_lo[(PROD == 3) ? FILL_IT : 1];
-
-  // `enable == false` issues the same loads against an empty descriptor (all zeros, no memory traffic): the fetch stays
-  // straight-line code, so the compiler can keep it in flight behind a COUNTED vmcnt instead of draining at a join
-  auto load_act = [&](int q, bool enable) {
-    const int planes_left = min(p.cin_planes - q * NPL, NPL);  // >= 1
-    const uint32_t nbytes = enable ? (uint32_t)planes_left * plane_bytes : 0u;
-    const int64_t chunk_off = (int64_t)q * NPL * p.in_plane_stride * 16;
-    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)(f_hi + chunk_off), 0, nbytes, 0x00020000);
-#pragma unroll
-    for (int it = 0; it < FILL_IT; ++it) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rh, foff[it], 0, 0);
-      st_hi[it] = make_uint4(v[0], v[1], v[2], v[3]);
-    }
-    if (PROD == 3) {
-      const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(f_lo + chunk_off), 0, nbytes, 0x00020000);
-#pragma unroll
-      for (int it = 0; it < FILL_IT; ++it) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rl, foff[it], 0, 0);
-        st_lo[it] = make_uint4(v[0], v[1], v[2], v[3]);
-      }
-    }
-  };
-  auto store_act = [&]() {
-#pragma unroll
-    for (int it = 0; it < FILL_IT; ++it) {
-      const int u = it * NTHREADS + tid;
-      if (u < ACT_UNITS) {
-        s_act[u] = st_hi[it];
-        if (PROD == 3) s_act[ACT_UNITS + u] = st_lo[it];
-      }
-    }
-  };
+  // =========================== COMPUTE WAVES ===========================
+  const int wct = wave / WPX;        // which cout group
+  const int wpx = wave - wct * WPX;  // which group of 4 rows
+  const int li = lane & 15;
+  const int lg = lane >> 4;
 
   // ---- weights: every wave streams ITS OWN A fragments (cout tiles 2*wct, 2*wct+1 of this slab) straight from the
   //      L2-resident packed blob into VGPRs, one tap ahead.  No LDS, no barrier: waves never share weight registers. ----
@@ -316,8 +138,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_kernel(const rsa_conv_params
   uint32_t woff[CTW];  // byte offset of this lane's fragment of (step 0, cout tile c, hi); 0xFFFFFFFF when the tile does not exist
 #pragma unroll
   for (int c = 0; c < CTW; ++c) {
-    const int ctg = slab * NCT + wct * 2 + c;
-    woff[c] = (wct * 2 + c < NCT && ctg < ct_total) ? (uint32_t)((ctg * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
+    const int ctg = slab * NCT + wct * CTW + c;
+    woff[c] = (wct * CTW + c < NCT && ctg < ct_total) ? (uint32_t)((ctg * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
   }
   const uint32_t wstep = (uint32_t)ct_total * NHL * 64 * 16;  // bytes per step
   bf16x8 wc[CTW][NHL];  // fragments of the tap being multiplied
@@ -327,9 +149,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_kernel(const rsa_conv_params
     for (int c = 0; c < CTW; ++c)
 #pragma unroll
       for (int hl = 0; hl < NHL; ++hl) {
-        // a missing cout tile keeps offset 0xFFFFFFFF (s*wstep is far below the wrap) -> zeros from the range check
-        const uint32_t off = woff[c];
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, off, (uint32_t)s * wstep + (uint32_t)hl * 1024u, 0);
+        // a missing cout tile keeps voffset 0xFFFFFFFF -> out of range -> zeros from the range check
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, woff[c], (uint32_t)s * wstep + (uint32_t)hl * 1024u, 0);
         wn[c][hl] = __builtin_bit_cast(bf16x8, v);
       }
   };
@@ -340,79 +161,83 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_kernel(const rsa_conv_params
 #pragma unroll
     for (int ct = 0; ct < CTW; ++ct) acc[pt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // B-fragment unit of (pixel-tile pt, tap 0,0) for this lane
+  // B-fragment unit of (pixel-tile 0, tap 0,0) for this lane
   const int bunit0 = lg * PS + (wpx * 4) * IW + li;
 
-  // ---- persistent loop over this workgroup's tiles; the (tile, chunk) stream is prefetched one item ahead,
-  //      so only the very first tile of a workgroup exposes its global-load latency ----
-  int tile = blockIdx.x;
-  if (tile >= num_tiles) return;
-  load_w(0);  // weights first: vmcnt retires in order
-  set_fill_tile(tile);
-  load_act(0, true);
-  int q = 0;
-  while (true) {
-    __syncthreads();  // every wave is done reading the previous item's halo tile
-    store_act();
-    __syncthreads();
-    const bool last_chunk = (q == nchunks - 1);
-    const int ntile = tile + (int)gridDim.x;
-    const bool more = !last_chunk || (ntile < num_tiles);
-    // software pipeline over the 8 pixel tiles: fragments of (t, pt+1) are read from LDS while (t, pt) multiplies
-    bf16x8 bh = *(const bf16x8*)&s_act[bunit0];
-    bf16x8 bl;
-    if (PROD == 3) bl = *(const bf16x8*)&s_act[ACT_UNITS + bunit0];
+  load_w(0);
+  int k = 0;
+  for (int tile = blockIdx.x; tile < num_tiles; tile += (int)gridDim.x) {
+    for (int q = 0; q < nchunks; ++q, ++k) {
+#ifndef RSA_ABL_NOBAR
+      __syncthreads();  // buffer (k & 1) has landed; everyone finished reading the other buffer one item ago
+#endif
+      const uint4* sa = &s_act[k & 1][0];
+      // software pipeline over the (tap, pixel-tile group) steps of the chunk: the B fragments of step i+LDS_DEPTH are
+      // read from LDS while step i multiplies.  A step covers GP pixel tiles with GP*CTW == 2 accumulator tiles, and its
+      // MFMAs are issued product-major, so two dependent MFMAs on one accumulator are never back to back.
+      constexpr int GP = 2 / CTW;          // pixel tiles per step (1 when the wave owns 2 cout tiles, else 2)
+      constexpr int SPT = 8 / GP;          // steps per tap
+      constexpr int NSTEP = T * SPT;
+      constexpr int LDS_DEPTH = 2;
+      bf16x8 rh[LDS_DEPTH + 1][GP], rl[LDS_DEPTH + 1][GP];
+      auto frag_unit = [&](int i, int g) -> int {
+        const int t = i / SPT, pt = (i - t * SPT) * GP + g;
+        const int dy = t / KS, dx = t - (t / KS) * KS;
+        return bunit0 + ((pt >> 1) + dy) * IW + (pt & 1) * 16 + dx;
+      };
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const int s = q * T + t;
+      for (int i = 0; i < LDS_DEPTH && i < NSTEP; ++i)
 #pragma unroll
-      for (int c = 0; c < CTW; ++c)
-#pragma unroll
-        for (int hl = 0; hl < NHL; ++hl) wc[c][hl] = wn[c][hl];
-      load_w(s + 1 < nsteps ? s + 1 : 0);  // next tap's weights (wraps to step 0 of the next tile)
-      if (t == 0) {
-        if (last_chunk) set_fill_tile(ntile);
-        load_act(last_chunk ? 0 : q + 1, more);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int pt = 0; pt < 8; ++pt) {
-        // next fragment: (t, pt+1), or (t+1, 0) across the tap boundary
-        const int nt = (pt == 7) ? t + 1 : t;
-        const int npt = (pt == 7) ? 0 : pt + 1;
-        bf16x8 nbh = bh, nbl = bh;
-        if (nt < T) {
-          const int ndy = nt / KS, ndx = nt - (nt / KS) * KS;
-          const int u = bunit0 + ((npt >> 1) + ndy) * IW + (npt & 1) * 16 + ndx;
-          nbh = *(const bf16x8*)&s_act[u];
-          if (PROD == 3) nbl = *(const bf16x8*)&s_act[ACT_UNITS + u];
+        for (int g = 0; g < GP; ++g) {
+          rh[i][g] = *(const bf16x8*)&sa[frag_unit(i, g)];
+          if (PROD == 3) rl[i][g] = *(const bf16x8*)&sa[ACT_UNITS + frag_unit(i, g)];
         }
-        if (PROD == 3) {
 #pragma unroll
-          for (int ct = 0; ct < CTW; ++ct) {
-            acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ct][NHL - 1], bh, acc[pt][ct], 0, 0, 0);
-            acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ct][0], bl, acc[pt][ct], 0, 0, 0);
-            acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ct][0], bh, acc[pt][ct], 0, 0, 0);
+      for (int i = 0; i < NSTEP; ++i) {
+        const int t = i / SPT, sp = i - t * SPT;
+        if (sp == 0) {
+          const int s = q * T + t;
+#pragma unroll
+          for (int c = 0; c < CTW; ++c)
+#pragma unroll
+            for (int hl = 0; hl < NHL; ++hl) wc[c][hl] = wn[c][hl];
+#ifndef RSA_ABL_NOW
+          load_w(s + 1 < nsteps ? s + 1 : 0);  // next tap's weights (wraps to step 0 of the next tile)
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#ifdef RSA_ABL_NOLDS
+        if (false) {
+#else
+        if (i + LDS_DEPTH < NSTEP) {
+#endif
+#pragma unroll
+          for (int g = 0; g < GP; ++g) {
+            const int u = frag_unit(i + LDS_DEPTH, g);
+            rh[(i + LDS_DEPTH) % (LDS_DEPTH + 1)][g] = *(const bf16x8*)&sa[u];
+            if (PROD == 3) rl[(i + LDS_DEPTH) % (LDS_DEPTH + 1)][g] = *(const bf16x8*)&sa[ACT_UNITS + u];
           }
-        } else {
-#pragma unroll
-          for (int ct = 0; ct < CTW; ++ct)
-            acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ct][0], bh, acc[pt][ct], 0, 0, 0);
         }
-        bh = nbh;
-        if (PROD == 3) bl = nbl;
-        // issue order inside the step: the next fragment reads first, then this step's MFMAs (the reads then have
-        // the whole MFMA group to land; the waits become counted lgkmcnt(NHL))
-        __builtin_amdgcn_sched_group_barrier(0x100, NHL, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, (PROD == 3 ? 3 : 1) * CTW, 0);
+        constexpr int NPR = (PROD == 3) ? 3 : 1;
+#pragma unroll
+        for (int pr = 0; pr < NPR; ++pr)
+#pragma unroll
+          for (int g = 0; g < GP; ++g)
+#pragma unroll
+            for (int ct = 0; ct < CTW; ++ct) {
+              const int pt = sp * GP + g;
+              // products in increasing magnitude: w_lo*a_hi, w_hi*a_lo, w_hi*a_hi
+              const bf16x8 wf = (PROD == 3 && pr == 0) ? wc[ct][NHL - 1] : wc[ct][0];
+              const bf16x8 bf = (PROD == 3 && pr == 1) ? rl[i % (LDS_DEPTH + 1)][g] : rh[i % (LDS_DEPTH + 1)][g];
+              acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, bf, acc[pt][ct], 0, 0, 0);
+            }
+        // issue order inside the step: the prefetch reads first, then this step's MFMAs
+        if (i + LDS_DEPTH < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, NHL * GP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NPR * GP * CTW, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (!last_chunk) {
-      ++q;
-      continue;
-    }
-    // ---- tile finished: epilogue for `tile`, then move on (next tile's first chunk is already in flight) ----
+    // ---- tile finished: epilogue (the loader is already streaming the next tile) ----
     {
       const int n = tile / tiles_img;
       const int tr = tile - n * tiles_img;
@@ -424,15 +249,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_kernel(const rsa_conv_params
     for (int pt = 0; pt < 8; ++pt)
 #pragma unroll
       for (int ct = 0; ct < CTW; ++ct) acc[pt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    tile = ntile;
-    q = 0;
-    if (tile >= num_tiles) break;
   }
 }
 
 template <int KS, int NCT, int PROD, int UP, int OUTK>
 static int launch_one(const rsa_conv_params& p, hipStream_t stream) {
-  using G = Geo<KS, NCT>;
+  using G = GeoLW<KS, NCT>;
   const int tiles_x = (p.W + G::TW - 1) / G::TW;
   const int tiles_y = (p.H + G::TH - 1) / G::TH;
   const int ct_total = (p.cout + 15) / 16;
@@ -444,7 +266,7 @@ static int launch_one(const rsa_conv_params& p, hipStream_t stream) {
   if (resident == 0) {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_kernel<KS, NCT, PROD, UP, OUTK>, NTHREADS, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_kernel<KS, NCT, PROD, UP, OUTK>, G::NTHR, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipGetLastError();
     resident = per_cu * prop.multiProcessorCount;
   }
@@ -452,12 +274,26 @@ static int launch_one(const rsa_conv_params& p, hipStream_t stream) {
   if (gx < 1) gx = 1;
   if (gx > num_tiles) gx = (int)num_tiles;
   dim3 grid((unsigned)gx, (unsigned)slabs, 1);
-  hipLaunchKernelGGL((conv_kernel<KS, NCT, PROD, UP, OUTK>), grid, dim3(NTHREADS), 0, stream, p);
+  hipLaunchKernelGGL((conv_kernel<KS, NCT, PROD, UP, OUTK>), grid, dim3(G::NTHR), 0, stream, p);
   return (int)hipGetLastError();
 }
 
+// register-staged schedule (conv_rs.hip), explicitly instantiated there
+template <int KS, int NCT, int PROD, int UP, int OUTK>
+int launch_rs(const rsa_conv_params& p, hipStream_t stream);
+extern template int launch_rs<3, 1, 3, 0, 0>(const rsa_conv_params&, hipStream_t);
+extern template int launch_rs<3, 2, 3, 0, 0>(const rsa_conv_params&, hipStream_t);
+extern template int launch_rs<3, 1, 3, 1, 0>(const rsa_conv_params&, hipStream_t);
+extern template int launch_rs<3, 2, 3, 1, 0>(const rsa_conv_params&, hipStream_t);
+
 template <int KS, int PROD, int UP, int OUTK>
 static int launch_nct2(const rsa_conv_params& p, int nct, hipStream_t stream) {
+  // schedule choice (measured, profiles/r01_b_conv_microbench.txt): split-bf16 k3 layers with <= 2 cout tiles run faster as two
+  // independent register-staged workgroups per CU; everything else uses the loader-wave schedule below
+  if constexpr (KS == 3 && PROD == 3 && OUTK == 0) {
+    if (nct == 1) return launch_rs<3, 1, 3, UP, 0>(p, stream);
+    if (nct == 2) return launch_rs<3, 2, 3, UP, 0>(p, stream);
+  }
   switch (nct) {
     case 1:
       return launch_one<KS, 1, PROD, UP, OUTK>(p, stream);
