@@ -78,6 +78,18 @@ def cpu_baseline(sd, crop: int) -> dict:
     }
 
 
+def measured_traffic():
+    """HBM bytes per conv launch from the committed rocprofv3 PMC summary (tools/hbm_traffic.py; separate FETCH_SIZE / WRITE_SIZE
+    passes of this same command, gfx950 x2 FETCH correction).  Counters cannot be read from inside the timed process."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_hbm_traffic.json')))
+    if not files:
+        return None, None
+    rec = json.load(open(files[-1]))
+    return rec.get('traffic_GB_per_launch', 0) * 1e9, os.path.basename(files[-1])
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -165,6 +177,7 @@ def main():
         flop = 2 * macs * H * W
         achieved_tf = flop / kern_s / 1e12
         achieved_gbs = HBM_B_PER_OUT_PX * out_px / kern_s / 1e9
+        traffic, traffic_src = measured_traffic() if (args.precision == 'bf16x3' and (H, W, args.blocks) == (1080, 1920, 23)) else (None, None)
         res = {
             'metric': 'output megapixels/sec, RealESRGAN-x4plus 1080p\u21924K, 1/2/4/8 MI355X',
             'value': round(value, 3),
@@ -192,8 +205,9 @@ def main():
                 'peak': MFMA_PEAK_TFLOPS,
                 'unit': 'TFLOP/s',
                 'frac': round(achieved_tf / MFMA_PEAK_TFLOPS, 4),
-                'traffic': None,
-                'kernel': 'rsa::conv_kernel<KS,NCT,PROD,UP> (all conv launches of one forward)',
+                'traffic': traffic,
+                'traffic_unit': 'HBM bytes per launch (avg over the 351 conv launches), from ' + traffic_src if traffic else None,
+                'kernel': 'rsa::conv_kernel / conv_kernel_rs <KS,NCT,PROD,UP,OUTK> (all 351 conv launches of one forward)',
                 'avg_launch_us': None if not n_launch else round(kern_s / n_launch * 1e6, 2),
                 'mfma_issued_frac': round(achieved_tf * (3 if args.precision == 'bf16x3' else 1) / MFMA_PEAK_TFLOPS, 4),
             },

@@ -52,7 +52,7 @@ __global__ __launch_bounds__((GeoLW<KS, NCT>::NTHR), (GeoLW<KS, NCT>::NCW == 8 ?
   const int tiles_y = (p.H + TH - 1) / TH;
   const int tiles_img = tiles_x * tiles_y;
   const int num_tiles = tiles_img * p.batch;
-  const int slab = blockIdx.y;
+  const int nslabs = (((p.cout + 15) >> 4) + NCT - 1) / NCT;  // cout slabs of one tile run back to back (halo tile re-read from L2)
   const int inW = UP ? (p.W >> 1) : p.W;
   const int nchunks = (p.cin_planes + NPL - 1) / NPL;
   const int nsteps = nchunks * T;
@@ -95,7 +95,8 @@ __global__ __launch_bounds__((GeoLW<KS, NCT>::NTHR), (GeoLW<KS, NCT>::NCW == 8 ?
         }
         doff[it] = ok ? (uint32_t)pl * plane_units + (uint32_t)iy * (uint32_t)inW + (uint32_t)ix : 0xFFFFFFFFu;
       }
-      for (int q = 0; q < nchunks; ++q, ++k) {
+      for (int sq = 0; sq < nslabs * nchunks; ++sq, ++k) {
+        const int q = sq % nchunks;
 #ifdef RSA_ABL_NOBAR
         continue;
 #endif
@@ -136,11 +137,14 @@ __global__ __launch_bounds__((GeoLW<KS, NCT>::NTHR), (GeoLW<KS, NCT>::NCW == 8 ?
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.w_packed, 0, (uint32_t)((int64_t)nsteps * ct_total * NHL * 64 * 16), 0x00020000);
   uint32_t woff[CTW];  // byte offset of this lane's fragment of (step 0, cout tile c, hi); 0xFFFFFFFF when the tile does not exist
+  auto set_slab = [&](int slab) {
 #pragma unroll
-  for (int c = 0; c < CTW; ++c) {
-    const int ctg = slab * NCT + wct * CTW + c;
-    woff[c] = (wct * CTW + c < NCT && ctg < ct_total) ? (uint32_t)((ctg * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
-  }
+    for (int c = 0; c < CTW; ++c) {
+      const int ctg = slab * NCT + wct * CTW + c;
+      woff[c] = (wct * CTW + c < NCT && ctg < ct_total) ? (uint32_t)((ctg * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
+    }
+  };
+  set_slab(0);
   const uint32_t wstep = (uint32_t)ct_total * NHL * 64 * 16;  // bytes per step
   bf16x8 wc[CTW][NHL];  // fragments of the tap being multiplied
   bf16x8 wn[CTW][NHL];  // fragments of the next tap, in flight
@@ -167,6 +171,7 @@ __global__ __launch_bounds__((GeoLW<KS, NCT>::NTHR), (GeoLW<KS, NCT>::NCW == 8 ?
   load_w(0);
   int k = 0;
   for (int tile = blockIdx.x; tile < num_tiles; tile += (int)gridDim.x) {
+   for (int slab = 0; slab < nslabs; ++slab) {
     for (int q = 0; q < nchunks; ++q, ++k) {
 #ifndef RSA_ABL_NOBAR
       __syncthreads();  // buffer (k & 1) has landed; everyone finished reading the other buffer one item ago
@@ -202,7 +207,13 @@ __global__ __launch_bounds__((GeoLW<KS, NCT>::NTHR), (GeoLW<KS, NCT>::NCW == 8 ?
 #pragma unroll
             for (int hl = 0; hl < NHL; ++hl) wc[c][hl] = wn[c][hl];
 #ifndef RSA_ABL_NOW
-          load_w(s + 1 < nsteps ? s + 1 : 0);  // next tap's weights (wraps to step 0 of the next tile)
+          if (s + 1 < nsteps) {
+            load_w(s + 1);  // next tap's weights
+          } else {
+            set_slab(slab + 1 < nslabs ? slab + 1 : 0);  // last step: prefetch step 0 of the next slab / next tile
+            load_w(0);
+            set_slab(slab);
+          }
 #endif
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -249,6 +260,8 @@ __global__ __launch_bounds__((GeoLW<KS, NCT>::NTHR), (GeoLW<KS, NCT>::NCW == 8 ?
     for (int pt = 0; pt < 8; ++pt)
 #pragma unroll
       for (int ct = 0; ct < CTW; ++ct) acc[pt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    set_slab(slab + 1 < nslabs ? slab + 1 : 0);
+   }
   }
 }
 
@@ -270,10 +283,10 @@ static int launch_one(const rsa_conv_params& p, hipStream_t stream) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipGetLastError();
     resident = per_cu * prop.multiProcessorCount;
   }
-  int gx = resident / slabs;
-  if (gx < 1) gx = 1;
+  (void)slabs;  // cout slabs are looped inside the kernel
+  int gx = resident;
   if (gx > num_tiles) gx = (int)num_tiles;
-  dim3 grid((unsigned)gx, (unsigned)slabs, 1);
+  dim3 grid((unsigned)gx, 1, 1);
   hipLaunchKernelGGL((conv_kernel<KS, NCT, PROD, UP, OUTK>), grid, dim3(G::NTHR), 0, stream, p);
   return (int)hipGetLastError();
 }
