@@ -177,6 +177,10 @@ __device__ __forceinline__ void epilogue(const rsa_conv_params& p, const f32x4 (
             ((__bf16*)p.out_nchw)[idx] = (__bf16)o;
         }
       }
+      // keep the 8*CTW fragment epilogues from being interleaved by the scheduler: interleaving them costs more registers
+      // than the 168-VGPR budget of the 9-wave schedule has and turns the epilogue into scratch traffic
+      // (in-process A/B, profiles/r01_h_ab_epilogue_serial.txt: +2..4 % on bf16x3 layers)
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }

@@ -177,6 +177,9 @@ __global__ __launch_bounds__((GeoLW<KS, NCT>::NTHR), (GeoLW<KS, NCT>::NCW == 8 ?
       __syncthreads();  // buffer (k & 1) has landed; everyone finished reading the other buffer one item ago
 #endif
       const uint4* sa = &s_act[k & 1][0];
+#ifdef RSA_ABL_NOMFMA
+      if (k >= 0) continue;  // timing-only build: loader throughput with idle compute waves
+#endif
       // software pipeline over the (tap, pixel-tile group) steps of the chunk: the B fragments of step i+LDS_DEPTH are
       // read from LDS while step i multiplies.  A step covers GP pixel tiles with GP*CTW == 2 accumulator tiles, and its
       // MFMAs are issued product-major, so two dependent MFMAs on one accumulator are never back to back.
