@@ -136,10 +136,12 @@ int rsa_conv_cout_tiles(int32_t cout);
  * Replaces the implicit NCHW read of the first conv, `(x - mean) * img_range` (archs/span/arch.py:232-234,
  * archs/swinir/arch.py:966-967) and, when H > src_h or W > src_w, the right/bottom REFLECT padding of
  * pad_to_multiple (utilities/padding.py:24-29; SwinIR.check_image_size).  Channels padded to 8 with zeros.
+ * unshuffle = r > 1 additionally fuses torch.pixel_unshuffle(x, r) (RRDBNet x2plus/x1 front end, archs/esrgan/arch.py:130-137):
+ * the planes then hold C*r*r channels of an (H x W) grid covering H*r x W*r source pixels.
  */
 int rsa_nchw_to_planes(const void* x, int32_t dtype, int32_t batch, int32_t C, int32_t H, int32_t W, int32_t src_h, int32_t src_w,
-                       const float* mean, float scale, void* out_hi, void* out_lo, int64_t out_plane_stride, int64_t out_batch_stride,
-                       void* stream);
+                       int32_t unshuffle, const float* mean, float scale, void* out_hi, void* out_lo, int64_t out_plane_stride,
+                       int64_t out_batch_stride, void* stream);
 
 /* split planes / f32 NCHW4c -> plain NCHW (debug + parity of intermediates) */
 int rsa_planes_to_nchw(const void* hi, const void* lo, int64_t plane_stride, int64_t batch_stride, int32_t batch,

@@ -16,7 +16,6 @@ from __future__ import annotations
 import math
 
 import torch
-import torch.nn.functional as F
 
 from ...engine import lib as L
 from ...engine import ops
@@ -156,13 +155,9 @@ class RRDBNet(EngineModule):
         pool = [plan.f32map(n, nf, h, w) for _ in range(4)]
         lrelu = dict(act=L.ACT_LRELU, act_param=0.2)
 
-        holder = {}
-
         def set_input(x):
-            if sf:
-                x = F.pixel_unshuffle(F.pad(x, (0, pad_w, 0, pad_h), 'reflect'), sf)
-            holder['x'] = x
-            ops.nchw_to_planes(x, x_pl)
+            # reflect padding + pixel_unshuffle (when the checkpoint has the unshuffle front end) happen inside the layout kernel
+            ops.nchw_to_planes(x, x_pl, unshuffle=sf or 1)
 
         # fea conv (arch.py:74-80): split planes into workspace 0 and the f32 residual stream
         plan.conv(ops.conv_params(W['model.0'], x_pl, h, w, out=ws[0], out_plane_off=0, out_f32=fea))
@@ -225,7 +220,6 @@ class RRDBNet(EngineModule):
 
         def get_output():
             y = out_buf.pop('y')
-            holder.clear()
             if sf:
                 y = y[:, :, : h_in * self.scale, : w_in * self.scale]
             return y

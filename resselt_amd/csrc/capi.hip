@@ -30,9 +30,14 @@ __device__ __forceinline__ float ld_as_float(const void* p, int64_t i) {
 // one thread per (n, plane, y, x) unit: gathers 8 channels of one pixel from the plain NCHW tensor
 // (H, W) = size of the planes; (srcH, srcW) <= (H, W) = size of x: rows/columns past the source are filled by REFLECTION
 // (F.pad(..., 'reflect') to the right/bottom, resselt/utilities/padding.py:24-29 as used by SwinIR.check_image_size)
-__global__ void nchw_to_planes_kernel(const void* x, int dtype, int batch, int C, int H, int W, int srcH, int srcW, const float* mean,
-                                      float scale, void* out_hi, void* out_lo, int64_t plane_stride, int64_t batch_stride) {
-  const int planes = (C + 7) >> 3;
+// unshuffle = r > 1: torch.pixel_unshuffle(x, r) fused into the read: plane channel c*r*r + i*r + j at (y, x) comes from source
+// channel c at (y*r + i, x*r + j) (RRDBNet x2plus / x1 front end, archs/esrgan/arch.py:130-137); C is then the SOURCE channel count.
+__global__ void nchw_to_planes_kernel(const void* x, int dtype, int batch, int C, int H, int W, int srcH, int srcW, int unshuffle,
+                                      const float* mean, float scale, void* out_hi, void* out_lo, int64_t plane_stride,
+                                      int64_t batch_stride) {
+  const int r2 = unshuffle * unshuffle;
+  const int Cp = C * r2;  // channels of the planes
+  const int planes = (Cp + 7) >> 3;
   const int64_t HW = (int64_t)H * W;
   const int64_t sHW = (int64_t)srcH * srcW;
   const int64_t total = (int64_t)batch * planes * HW;
@@ -41,24 +46,26 @@ __global__ void nchw_to_planes_kernel(const void* x, int dtype, int batch, int C
     const int64_t t = idx / HW;
     const int pl = (int)(t % planes);
     const int n = (int)(t / planes);
-    int sy = (int)(pix / W), sx = (int)(pix % W);
-    if (sy >= srcH) sy = 2 * (srcH - 1) - sy;
-    if (sx >= srcW) sx = 2 * (srcW - 1) - sx;
-    const int64_t spix = (int64_t)sy * srcW + sx;
+    const int py = (int)(pix / W), px = (int)(pix % W);
     bf16x8 h, l;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int c = pl * 8 + j;
+      const int cp = pl * 8 + j;
       float v = 0.f;
-      if (c < C) {
-        const int64_t src = ((int64_t)n * C + c) * sHW + spix;
+      if (cp < Cp) {
+        const int c = cp / r2;
+        const int rem = cp - c * r2;
+        int sy = py * unshuffle + rem / unshuffle, sx = px * unshuffle + rem % unshuffle;
+        if (sy >= srcH) sy = 2 * (srcH - 1) - sy;
+        if (sx >= srcW) sx = 2 * (srcW - 1) - sx;
+        const int64_t src = ((int64_t)n * C + c) * sHW + (int64_t)sy * srcW + sx;
         if (dtype == RSA_F32)
           v = ld_as_float<float>(x, src);
         else if (dtype == RSA_F16)
           v = ld_as_float<_Float16>(x, src);
         else
           v = ld_as_float<__bf16>(x, src);
-        if (mean != nullptr) v -= mean[c];
+        if (mean != nullptr) v -= mean[c];  // per SOURCE channel
         v *= scale;
       }
       const __bf16 hb = (__bf16)v;
@@ -133,16 +140,20 @@ int64_t rsa_packed_weight_bytes(int32_t cout, int32_t cin_planes, int32_t ksize,
 }
 
 int rsa_nchw_to_planes(const void* x, int32_t dtype, int32_t batch, int32_t C, int32_t H, int32_t W, int32_t src_h, int32_t src_w,
-                       const float* mean, float scale, void* out_hi, void* out_lo, int64_t out_plane_stride, int64_t out_batch_stride,
-                       void* stream) {
+                       int32_t unshuffle, const float* mean, float scale, void* out_hi, void* out_lo, int64_t out_plane_stride,
+                       int64_t out_batch_stride, void* stream) {
+  if (unshuffle < 1) return rsa::set_error(RSA_E_ARG, "nchw_to_planes: unshuffle must be >= 1");
   if (x == nullptr || out_hi == nullptr || batch < 1 || C < 1 || H < 1 || W < 1) return rsa::set_error(RSA_E_ARG, "nchw_to_planes: bad argument");
-  if (src_h < 1 || src_w < 1 || src_h > H || src_w > W || H - src_h >= src_h || W - src_w >= src_w)
-    return rsa::set_error(RSA_E_ARG, "nchw_to_planes: source size must satisfy src <= plane size < 2*src (reflect padding)");
+  {
+    const int64_t fh = (int64_t)H * unshuffle, fw = (int64_t)W * unshuffle;  // full-resolution size the planes cover
+    if (src_h < 1 || src_w < 1 || src_h > fh || src_w > fw || fh - src_h >= src_h || fw - src_w >= src_w)
+      return rsa::set_error(RSA_E_ARG, "nchw_to_planes: source size must satisfy src <= plane size * unshuffle < 2*src (reflect padding)");
+  }
   if (dtype < RSA_F32 || dtype > RSA_BF16) return rsa::set_error(RSA_E_ARG, "nchw_to_planes: bad dtype");
   if (((uintptr_t)out_hi | (uintptr_t)out_lo) & 15) return rsa::set_error(RSA_E_ALIGN, "nchw_to_planes: outputs must be 16-byte aligned");
-  const int64_t total = (int64_t)batch * ((C + 7) / 8) * H * W;
+  const int64_t total = (int64_t)batch * ((C * unshuffle * unshuffle + 7) / 8) * H * W;
   hipLaunchKernelGGL(rsa::nchw_to_planes_kernel, dim3(rsa::grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, dtype, batch, C, H, W,
-                     src_h, src_w, mean, scale, out_hi, out_lo, out_plane_stride, out_batch_stride);
+                     src_h, src_w, unshuffle, mean, scale, out_hi, out_lo, out_plane_stride, out_batch_stride);
   const int rc = (int)hipGetLastError();
   return rc ? rsa::set_error(rc, "nchw_to_planes: launch failed") : RSA_OK;
 }

@@ -168,7 +168,7 @@ def load() -> C.CDLL:
     lib.rsa_packed_weight_bytes.argtypes = [C.c_int32] * 4
     lib.rsa_packed_weight_bytes.restype = C.c_int64
     lib.rsa_nchw_to_planes.argtypes = [
-        C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_float,
+        C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_float,
         C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
     ]  # fmt: skip
     lib.rsa_nchw_to_planes.restype = C.c_int

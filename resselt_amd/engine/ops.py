@@ -142,21 +142,23 @@ def run_convs(params: list[L.ConvParams], device) -> None:
     L.conv2d_list(params, current_stream_ptr(device))
 
 
-def nchw_to_planes(x: torch.Tensor, out: Planes, mean: torch.Tensor | None = None, scale: float = 1.0) -> None:
+def nchw_to_planes(x: torch.Tensor, out: Planes, mean: torch.Tensor | None = None, scale: float = 1.0, unshuffle: int = 1) -> None:
     """Plain [N,C,h,w] tensor -> split planes on the GPU (rsa_nchw_to_planes).
 
     ``out`` may be larger than ``x`` (up to 2x-1): the extra rows/columns are reflect-padded (SwinIR window padding).
+    ``unshuffle=r`` fuses ``pixel_unshuffle(x, r)``: ``out`` is then the (H/r x W/r) grid with C*r*r channels.
     """
     require_cuda(x, 'nchw_to_planes')
     if not x.is_contiguous():
         x = x.contiguous()
     n, c, h, w = x.shape
-    if out.n != n or out.h < h or out.w < w or out.planes < (c + 7) // 8:
+    r = unshuffle
+    if out.n != n or out.h * r < h or out.w * r < w or out.planes < (c * r * r + 7) // 8:
         raise ValueError('output planes do not match the input tensor')
     lib = L.load()
     L.check(
         lib.rsa_nchw_to_planes(
-            x.data_ptr(), rsa_dtype(x.dtype), n, c, out.h, out.w, h, w, None if mean is None else mean.data_ptr(), scale,
+            x.data_ptr(), rsa_dtype(x.dtype), n, c, out.h, out.w, h, w, r, None if mean is None else mean.data_ptr(), scale,
             out.hi_ptr(), out.lo_ptr(), out.plane_stride, out.batch_stride, C.c_void_p(current_stream_ptr(x.device)),
         ),
         'rsa_nchw_to_planes',

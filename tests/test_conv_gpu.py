@@ -183,6 +183,23 @@ def test_layout_kernels(device):
     assert (ops.planes_to_nchw(out, 5).cpu() - xh.float().cpu()).abs().max().item() <= 1e-5
 
 
+def test_layout_kernel_reflect_pad_and_unshuffle(device):
+    import torch.nn.functional as F2
+
+    x = _rand((2, 3, 21, 30), 51)
+    # reflect padding to a multiple of 8 (SwinIR.check_image_size)
+    out = tensors.Planes.empty(2, 1, 24, 32, device)
+    ops.nchw_to_planes(x.to(device), out)
+    ref = F2.pad(x, (0, 2, 0, 3), 'reflect')
+    assert (ops.planes_to_nchw(out, 3).cpu() - ref).abs().max().item() <= 1e-5
+    # reflect pad to even size + pixel_unshuffle(2) (RRDBNet x2plus front end)
+    out2 = tensors.Planes.empty(2, 2, 11, 15, device)
+    ops.nchw_to_planes(x.to(device), out2, unshuffle=2)
+    ref2 = F2.pixel_unshuffle(F2.pad(x, (0, 0, 0, 1), 'reflect'), 2)
+    got2 = ops.planes_to_nchw(out2, 16).cpu()
+    assert (got2[:, :12] - ref2).abs().max().item() <= 1e-5 and got2[:, 12:].abs().max().item() == 0.0
+
+
 def test_argument_errors(device):
     wts = ops.ConvWeights.from_oihw(torch.zeros(8, 8, 3, 3), None, 3, device=device)
     xin = tensors.Planes.empty(1, 1, 8, 8, device)

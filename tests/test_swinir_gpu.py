@@ -25,7 +25,7 @@ def _rand(shape, seed, scale=1.0):
     return (torch.rand(shape, generator=g) * 2 - 1) * scale
 
 
-@pytest.mark.parametrize('C_,h,w', [(240, 9, 13), (180, 8, 8), (60, 5, 70), (12, 3, 3)])
+@pytest.mark.parametrize('C_,h,w', [(240, 9, 13), (180, 8, 8), (60, 5, 70), (12, 3, 3), (256, 4, 5), (320, 6, 7)])
 def test_layernorm_kernel(device, C_, h, w):
     x = _rand((2, C_, h, w), 1, 3.0) + 0.5
     g, b = 1 + _rand((C_,), 2, 0.5), _rand((C_,), 3, 0.5)
