@@ -49,7 +49,8 @@ enum rsa_act {
   RSA_ACT_MISH = 2,  /* reference archs/spanplus/arch.py:121 (nn.Mish)                  */
   RSA_ACT_SILU = 3,  /* reference archs/span/arch.py:164 (nn.SiLU)                      */
   RSA_ACT_GELU = 4,  /* erf GELU, reference archs/swinir/arch.py:34-40 (nn.GELU)        */
-  RSA_ACT_SPAB_GATE = 5 /* y = (acc + res1) * (sigmoid(acc) - 0.5); spanplus/arch.py:126-127 */
+  RSA_ACT_SPAB_GATE = 5, /* y = (acc + res1) * (sigmoid(acc) - 0.5); spanplus/arch.py:126-127 */
+  RSA_ACT_PRELU = 6      /* per-channel slopes act_vec[cout]; nn.PReLU(num_parameters=C), compact/arch.py:42-52 */
 };
 
 /* dtype of plain NCHW tensors crossing the boundary */
@@ -111,6 +112,9 @@ typedef struct rsa_conv_params {
   int32_t pixel_shuffle;    /* r >= 1 (depth-to-space factor applied while storing out_nchw) */
   float out_scale;          /* out_nchw value = v * out_scale + out_shift[oc]  (SwinIR x/img_range + mean, */
   const float* out_shift;   /*   archs/swinir/arch.py:1013); NULL = none */
+  const float* act_vec;     /* RSA_ACT_PRELU: negative slopes, f32[round_up(cout,16)], 16-byte aligned */
+  const void* out_base;     /* optional with out_nchw: plain [N][cout/r^2][H][W] tensor of dtype out_dtype whose pixel (y,x) is
+                               ADDED to all r x r output pixels it covers (nearest-upsampled base image, compact/arch.py:61-64) */
 } rsa_conv_params;
 
 /* Launch `n` fused convolutions in order on `stream` (one host call per forward pass). */

@@ -19,6 +19,7 @@ constexpr int NPL = 4;  // planes per K chunk (32 channels = one MFMA K)
 __device__ __forceinline__ float act_apply(float v, int act, float prm) {
   switch (act) {
     case RSA_ACT_LRELU:
+    case RSA_ACT_PRELU:  // prm = this channel's slope
       return v >= 0.f ? v : v * prm;
     case RSA_ACT_MISH: {
       // torch: x * tanh(softplus(x)), softplus threshold 20
@@ -97,6 +98,8 @@ __device__ __forceinline__ void epilogue(const rsa_conv_params& p, const f32x4 (
     const int c0 = cbase + lg * 4;
     f32x4 bias = {0.f, 0.f, 0.f, 0.f};
     if (p.bias != nullptr) bias = ((const f32x4*)p.bias)[c0 >> 2];  // bias is padded to a multiple of 16
+    f32x4 slope = {0.f, 0.f, 0.f, 0.f};
+    if (p.act == RSA_ACT_PRELU) slope = ((const f32x4*)p.act_vec)[c0 >> 2];  // per-channel PReLU slopes, same padding
     const bool cvalid = c0 < cout8;
     const bool has_f32grp = c0 < (p4 << 2);
     // uniform bases for this cout tile
@@ -126,7 +129,7 @@ __device__ __forceinline__ void epilogue(const rsa_conv_params& p, const f32x4 (
           }
         } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act, p.act_param);
+          for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act, p.act == RSA_ACT_PRELU ? slope[r] : p.act_param);
           if (p.res1 != nullptr && has_f32grp) {
             const f32x4 rr = *(const f32x4*)(r1b + foff);
 #pragma unroll
@@ -152,7 +155,7 @@ __device__ __forceinline__ void epilogue(const rsa_conv_params& p, const f32x4 (
         if (p.out_f32 != nullptr && has_f32grp) *(f32x4*)(f32b + foff) = (f32x4){v[0], v[1], v[2], v[3]};
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act, p.act_param);
+        for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act, p.act == RSA_ACT_PRELU ? slope[r] : p.act_param);
         const int ps = p.pixel_shuffle > 1 ? p.pixel_shuffle : 1;
         const int oc_total = p.cout / (ps * ps);
         const int64_t oW = (int64_t)p.W * ps;
@@ -168,6 +171,15 @@ __device__ __forceinline__ void epilogue(const rsa_conv_params& p, const f32x4 (
           const int jj = rem - ii * ps;
           float o = v[r] * p.out_scale;
           if (p.out_shift != nullptr) o += p.out_shift[oc];
+          if (p.out_base != nullptr) {  // nearest-upsampled base image: the low-resolution pixel this output pixel sits in
+            const int64_t bi = (((int64_t)n * oc_total + oc) * p.H + y) * p.W + x;
+            if (p.out_dtype == RSA_F32)
+              o += ((const float*)p.out_base)[bi];
+            else if (p.out_dtype == RSA_F16)
+              o += (float)((const _Float16*)p.out_base)[bi];
+            else
+              o += (float)((const __bf16*)p.out_base)[bi];
+          }
           const int64_t idx = ((int64_t)n * oc_total + oc) * oHW + ((int64_t)y * ps + ii) * oW + ((int64_t)x * ps + jj);
           if (p.out_dtype == RSA_F32)
             ((float*)p.out_nchw)[idx] = o;

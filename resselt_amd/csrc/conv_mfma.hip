@@ -344,7 +344,9 @@ int conv_launch(const rsa_conv_params& p, hipStream_t stream) {
   if (p.in_hi == nullptr || p.w_packed == nullptr) return set_error(RSA_E_ARG, "conv: null input/weights");
   if (p.products == 3 && p.in_lo == nullptr) return set_error(RSA_E_ARG, "conv: products=3 needs in_lo");
   if (p.act == RSA_ACT_SPAB_GATE && p.res1 == nullptr) return set_error(RSA_E_ARG, "conv: SPAB gate needs res1");
-  if (p.act < 0 || p.act > RSA_ACT_SPAB_GATE) return set_error(RSA_E_ARG, "conv: bad act");
+  if (p.act < 0 || p.act > RSA_ACT_PRELU) return set_error(RSA_E_ARG, "conv: bad act");
+  if (p.act == RSA_ACT_PRELU && (p.act_vec == nullptr || ((uintptr_t)p.act_vec & 15))) return set_error(RSA_E_ARG, "conv: PReLU needs 16-byte aligned act_vec");
+  if (p.out_base != nullptr && p.out_nchw == nullptr) return set_error(RSA_E_ARG, "conv: out_base only applies to the out_nchw store");
   if (((uintptr_t)p.in_hi | (uintptr_t)p.in_lo | (uintptr_t)p.w_packed | (uintptr_t)p.out_hi | (uintptr_t)p.out_lo | (uintptr_t)p.out_f32 |
        (uintptr_t)p.res1 | (uintptr_t)p.res2) & 15)
     return set_error(RSA_E_ALIGN, "conv: pointers must be 16-byte aligned");

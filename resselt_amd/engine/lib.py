@@ -15,7 +15,7 @@ _LIB_NAME = 'libresselt_amd.so'
 _lib: Optional[C.CDLL] = None
 
 # enum rsa_act
-ACT_NONE, ACT_LRELU, ACT_MISH, ACT_SILU, ACT_GELU, ACT_SPAB_GATE = range(6)
+ACT_NONE, ACT_LRELU, ACT_MISH, ACT_SILU, ACT_GELU, ACT_SPAB_GATE, ACT_PRELU = range(7)
 # enum rsa_dtype
 F32, F16, BF16 = range(3)
 
@@ -55,6 +55,8 @@ class ConvParams(C.Structure):
         ('pixel_shuffle', C.c_int32),
         ('out_scale', C.c_float),
         ('out_shift', C.c_void_p),
+        ('act_vec', C.c_void_p),
+        ('out_base', C.c_void_p),
     ]
 
 

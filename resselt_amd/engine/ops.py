@@ -8,7 +8,7 @@ from dataclasses import dataclass
 import torch
 
 from . import lib as L
-from .pack import pack_conv_weights, pad_bias
+from .pack import pack_conv_weights, pad_bias  # noqa: F401  (pad_bias re-exported for the model files)
 from .tensors import Planes
 
 _TORCH_TO_RSA = {torch.float32: L.F32, torch.float16: L.F16, torch.bfloat16: L.BF16}
@@ -79,6 +79,8 @@ def conv_params(
     pixel_shuffle: int = 1,
     out_scale: float = 1.0,
     out_shift: torch.Tensor | None = None,
+    act_vec: torch.Tensor | None = None,
+    out_base: torch.Tensor | None = None,
 ) -> L.ConvParams:
     """Fill one ``rsa_conv_params``. ``H``, ``W`` are the OUTPUT size of the convolution."""
     p = L.ConvParams()
@@ -135,6 +137,14 @@ def conv_params(
         p.out_nchw = out_nchw.data_ptr()
         p.out_dtype = rsa_dtype(out_nchw.dtype)
         p.out_shift = None if out_shift is None else out_shift.data_ptr()
+        if out_base is not None:
+            if tuple(out_base.shape) != (x.n, exp[1], H, W) or out_base.dtype != out_nchw.dtype or not out_base.is_contiguous():
+                raise ValueError('out_base must be a contiguous [N, C_out, H, W] tensor of the output dtype')
+            p.out_base = out_base.data_ptr()
+    if act == L.ACT_PRELU:
+        if act_vec is None or act_vec.numel() < ((wts.cout + 15) // 16) * 16 or act_vec.dtype != torch.float32:
+            raise ValueError('PReLU needs f32 slopes padded to a multiple of 16')
+        p.act_vec = act_vec.data_ptr()
     return p
 
 

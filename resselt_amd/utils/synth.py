@@ -218,3 +218,15 @@ def swinir_state_dict(in_ch=3, embed_dim=60, depths=(2, 2), num_heads=(6, 6), wi
     else:
         _conv(sd, 'conv_last', in_ch, C, 3, seed)
     return sd
+
+
+def compact_state_dict(num_in_ch=3, num_feat=64, num_conv=16, upscale=4, seed=0):
+    """Keys of SRVGGNetCompact (archs/compact/arch.py:36-57): body.{2i} convs, body.{2i+1} PReLU slopes, last conv."""
+    sd: OrderedDict = OrderedDict()
+    cin = num_in_ch
+    for i in range(num_conv + 1):
+        _conv(sd, f'body.{2 * i}', num_feat, cin, 3, seed)
+        sd[f'body.{2 * i + 1}.weight'] = 0.25 + synth_tensor(f'body.{2 * i + 1}.weight', (num_feat,), 16, seed)  # slopes in (0, 0.5)
+        cin = num_feat
+    _conv(sd, f'body.{2 * (num_conv + 1)}', num_in_ch * upscale * upscale, num_feat, 3, seed)
+    return sd

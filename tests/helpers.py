@@ -28,7 +28,7 @@ def synth_state_dict(meta):
     if 'blocks' in kw:
         kw['blocks'] = tuple(kw['blocks'])
     fn = {'esrgan': synth.rrdbnet_state_dict, 'spanplus': synth.spanplus_state_dict, 'span': synth.span_state_dict,
-          'swinir': getattr(synth, 'swinir_state_dict', None)}[meta['arch']]  # fmt: skip
+          'swinir': getattr(synth, 'swinir_state_dict', None), 'compact': synth.compact_state_dict}[meta['arch']]  # fmt: skip
     return fn(seed=meta['seed'], **kw)
 
 
@@ -49,4 +49,8 @@ def oracle_forward(meta, sd, x):
         from oracle.swinir import swinir_forward
 
         return swinir_forward(sd, x)
+    if meta['arch'] == 'compact':
+        from oracle.compact import compact_forward
+
+        return compact_forward(sd, x)
     raise KeyError(meta['arch'])

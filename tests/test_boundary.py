@@ -128,7 +128,7 @@ def test_esrgan_roundtrip_and_new_arch_fix():
 
 def test_detection_claims_match_reference():
     meta, _ = load_golden('registry_claims')
-    ours = {'rrdbnet_old': 'ESRGAN', 'spanplus_ps': 'spanplus', 'spanplus_dys': 'spanplus', 'span': 'SPAN'}
+    ours = {'rrdbnet_old': 'ESRGAN', 'spanplus_ps': 'spanplus', 'spanplus_dys': 'spanplus', 'span': 'SPAN', 'compact': 'Compact', 'swinir': 'SwinIR'}
     for tag, uid in ours.items():
         assert meta['claims'][tag] == uid
     built = {
@@ -136,11 +136,12 @@ def test_detection_claims_match_reference():
         'spanplus_ps': synth.spanplus_state_dict(upsampler='ps'),
         'spanplus_dys': synth.spanplus_state_dict(upsampler='dys'),
         'span': synth.span_state_dict(),
+        'compact': synth.compact_state_dict(num_conv=2),
+        'swinir': synth.swinir_state_dict(),
     }
     for tag, sd in built.items():
         hit = [a.id for a in resselt_amd.archs.internal_registry if a.detect(sd)]
-        if hit:  # archs not built yet simply do not claim
-            assert hit[0] == ours[tag], tag
+        assert hit and hit[0] == ours[tag], tag
 
 
 def test_file_formats_and_restricted_pickle(tmp_path):

@@ -60,3 +60,17 @@ def test_span_eval_and_train_mode_agree(device):
     y_train = m(x)
     y_eval = m.eval()(x)
     assert torch.equal(y_train, y_eval)
+
+
+@pytest.mark.parametrize('name', golden_names('compact_'))
+def test_compact_matches_reference_vectors(device, name):
+    """SRVGGNetCompact: PReLU epilogue, PixelShuffle + nearest base image in the final store (first "next" row of SURVEY §8f)."""
+    meta, arr = load_golden(name)
+    sd = synth_state_dict(meta)
+    m = resselt_amd.load_from_state_dict(dict(sd)).to(device)
+    assert vars(m.parameters_info) == {k: meta['metadata'][k] for k in ('in_channels', 'out_channels', 'upscale', 'name')}
+    y = m(arr['x'].to(device))
+    assert y.shape == arr['y'].shape
+    assert (y.cpu() - arr['y']).abs().max().item() <= _tol(arr['y'])
+    yh = m(arr['x'].half().to(device))
+    assert yh.dtype == torch.float16 and (yh.float().cpu() - arr['y']).abs().max().item() <= 4e-3 * max(1.0, arr['y'].abs().max().item())

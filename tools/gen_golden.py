@@ -166,6 +166,17 @@ def span_cases():
     save('blocks_span', dict(arch='spanplus', seed=seed, synth={}), x=x, fold_w=c.eval_conv.weight.data, fold_b=c.eval_conv.bias.data, spab_out=out, spab_out1=out1)
 
 
+def compact_cases():
+    for name, kw, shape, seed in [
+        ('compact_x4_nf64_nc16_20x28', dict(num_feat=64, num_conv=16, upscale=4), (1, 3, 20, 28), 71),
+        ('compact_x2_nf32_nc4_b2_17x19', dict(num_feat=32, num_conv=4, upscale=2), (2, 3, 17, 19), 72),
+    ]:
+        sd = synth.compact_state_dict(seed=seed, **kw)
+        model = resselt.load_from_state_dict(dict(sd))
+        x = synth.synth_input(shape, seed)
+        save(name, dict(arch='compact', synth=kw, seed=seed, metadata=meta_of(model)), x=x, y=model(x))
+
+
 def registry_cases():
     """Detection order facts: which reference architecture claims each synthetic checkpoint."""
     claims = {}
@@ -174,6 +185,8 @@ def registry_cases():
         ('spanplus_ps', synth.spanplus_state_dict(upsampler='ps')),
         ('spanplus_dys', synth.spanplus_state_dict(upsampler='dys')),
         ('span', synth.span_state_dict()),
+        ('compact', synth.compact_state_dict(num_conv=2)),
+        ('swinir', synth.swinir_state_dict()),
     ):
         for arch in resselt.archs.internal_registry.store.values():
             if arch.detect(sd):
@@ -183,13 +196,15 @@ def registry_cases():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['esrgan', 'blocks', 'span', 'registry', 'swinir']
+    which = sys.argv[1:] or ['esrgan', 'blocks', 'span', 'compact', 'registry', 'swinir']
     if 'esrgan' in which:
         esrgan_cases()
     if 'blocks' in which:
         block_cases()
     if 'span' in which:
         span_cases()
+    if 'compact' in which:
+        compact_cases()
     if 'registry' in which:
         registry_cases()
     if 'swinir' in which:
