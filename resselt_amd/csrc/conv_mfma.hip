@@ -294,6 +294,8 @@ static int launch_one(const rsa_conv_params& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+int gemm_k1_launch(const rsa_conv_params& p, hipStream_t stream);  // gemm_k1.hip; -100 = not applicable
+
 // register-staged schedule (conv_rs.hip), explicitly instantiated there
 template <int KS, int NCT, int PROD, int UP, int OUTK>
 int launch_rs(const rsa_conv_params& p, hipStream_t stream);
@@ -360,6 +362,10 @@ int conv_launch(const rsa_conv_params& p, hipStream_t stream) {
     const int ps = p.pixel_shuffle > 1 ? p.pixel_shuffle : 1;
     if (p.cout % (ps * ps) != 0) return set_error(RSA_E_ARG, "conv: cout not divisible by pixel_shuffle^2");
     if (p.out_dtype < RSA_F32 || p.out_dtype > RSA_BF16) return set_error(RSA_E_ARG, "conv: bad out_dtype");
+  }
+  if (p.ksize == 1) {  // wide k1 layers (nn.Linear over tokens): weight-stationary GEMM schedule, gemm_k1.hip
+    const int g = gemm_k1_launch(p, stream);
+    if (g != -100) return g == 0 ? RSA_OK : set_error(g, "conv: gemm_k1 launch failed");
   }
   const int nct = conv_nct(p.cout);
   int rc;

@@ -1,0 +1,229 @@
+// gemm_k1.hip — weight-stationary schedule for 1x1 convolutions with many output channels (nn.Linear over tokens:
+// SwinIR qkv / proj / fc1 / fc2, resselt/archs/swinir/arch.py:34-40,141,168).
+//
+// A k1 layer has no tap reuse: the halo-tile schedules of conv_mfma.hip refill LDS for every 48-96 MFMAs and end up bound by
+// the LDS-DMA landing rate (profiles/r01_*: ~140 TFLOP/s issued).  Here the roles are swapped:
+//   * every wave keeps the A fragments (weights) of ITS cout tiles for the WHOLE reduction in registers
+//     (CTW cout tiles x NQ K-chunks x hi/lo = 128 VGPRs), loaded once per pass over the pixels;
+//   * pixels stream through LDS in tiles of 64 consecutive tokens x all input planes, double-buffered; all 8 waves issue the
+//     LDS-DMA of tile i+1 (each DMA instruction = one (plane, 64-pixel) row = 1 KiB contiguous in HBM), then multiply tile i;
+//     no other vector-memory instruction is issued in between, so the in-order vmcnt never drains the prefetch early;
+//   * one workgroup barrier per tile; 8 waves x CTW cout tiles = up to 256 output channels per pass (wider layers take
+//     ceil(cout / (128*CTW)) passes over the token map).
+#include "conv_common.h"
+
+namespace rsa {
+
+__device__ uint4 g_zero_unit_gk[4];  // source of zero units for lanes past the end of the token map (never written)
+
+constexpr int GK_WAVES = 8;
+
+// TP = pixels per tile (64, or 32 when the whole-K image of 64 pixels would not fit twice in LDS)
+template <int PROD, int CTW, int NQ, int GK_TP>
+__global__ __launch_bounds__(GK_WAVES * 64, 2) void gemm_k1_kernel(const rsa_conv_params p) {
+  constexpr int NHL = (PROD == 3) ? 2 : 1;
+  constexpr int NPT = GK_TP / 16;
+  // LDS image of one tile: [hi|lo][K-chunk q][plane in chunk 4][64 pixels] units; two buffers
+  constexpr int BUF_UNITS = NHL * NQ * 4 * GK_TP;
+  __shared__ uint4 s_x[2][BUF_UNITS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15;
+  const int lg = lane >> 4;
+
+  const int64_t HW = (int64_t)p.H * p.W;
+  const int tiles_img = (int)((HW + GK_TP - 1) / GK_TP);
+  const int num_tiles = tiles_img * p.batch;
+  const int nq = (p.cin_planes + 3) >> 2;  // <= NQ (checked on the host)
+  const int ct_total = (p.cout + 15) >> 4;
+  const int npass = (ct_total + GK_WAVES * CTW - 1) / (GK_WAVES * CTW);
+  if ((int)blockIdx.x >= num_tiles) return;
+
+  // planes past cin_planes inside the last chunk are never written by the DMA: zero them once in both buffers
+  // (their weights are zero, but 0 * stale-NaN would poison the accumulators)
+  for (int u = tid; u < 2 * BUF_UNITS; u += GK_WAVES * 64) (&s_x[0][0])[u] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.w_packed, 0, (uint32_t)((int64_t)nq * ct_total * NHL * 64 * 16), 0x00020000);
+  const uint32_t wstep = (uint32_t)ct_total * NHL * 64 * 16;  // bytes per K-chunk (k1: one tap per chunk)
+
+  // cooperative LDS-DMA of one tile: instruction j fills units [64j, 64j+64) of the image = row(s) (hl, plane) of GK_TP
+  // pixels; instructions are dealt round-robin to the 8 waves; rows of planes past cin_planes keep their zeros
+  constexpr int ROWS = NHL * NQ * 4;
+  constexpr int NINST = ROWS * GK_TP / 64;
+  auto issue_tile = [&](int tile, int buf) {
+    const int n = tile / tiles_img;
+    const int64_t pix0 = (int64_t)(tile - n * tiles_img) * GK_TP;
+    const uint4* bh = (const uint4*)p.in_hi + (int64_t)n * p.in_batch_stride + pix0;
+    const uint4* bl = (PROD == 3) ? (const uint4*)p.in_lo + (int64_t)n * p.in_batch_stride + pix0 : nullptr;
+    for (int j = wave; j < NINST; j += GK_WAVES) {
+      const int u = j * 64 + lane;
+      const int row = u / GK_TP, px = u - row * GK_TP;
+      const int hl = row / (NQ * 4);
+      const int pl = row - hl * (NQ * 4);
+      // wave-uniform skip of instructions that only cover missing planes (GK_TP divides 64: an instruction spans 64/GK_TP rows)
+      const int row_first = (j * 64) / GK_TP;
+      if (row_first - (row_first / (NQ * 4)) * (NQ * 4) >= p.cin_planes) continue;
+      const bool ok = pl < p.cin_planes && pix0 + px < HW;
+      const uint4* src = ok ? ((PROD == 3 && hl) ? bl : bh) + (int64_t)pl * p.in_plane_stride + px : (const uint4*)&g_zero_unit_gk[0];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)&s_x[buf][j * 64], 16, 0, 0);
+    }
+  };
+
+  const int p4 = (p.cout + 3) >> 2;
+  const int cout8 = (p.cout + 7) & ~7;
+
+  for (int pass = 0; pass < npass; ++pass) {
+    // ---- this wave's weights for the whole reduction ----
+    bf16x8 wr[CTW][NQ][NHL];
+    int ctg[CTW];
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) {
+      ctg[c] = (pass * GK_WAVES + wave) * CTW + c;
+      const uint32_t base = ctg[c] < ct_total ? (uint32_t)((ctg[c] * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int hl = 0; hl < NHL; ++hl) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, (q < nq) ? base : 0xFFFFFFFFu, (uint32_t)q * wstep + (uint32_t)hl * 1024u, 0);
+          wr[c][q][hl] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+
+    int tile = blockIdx.x;
+    int buf = 0;
+    issue_tile(tile, buf);
+    __syncthreads();  // vmcnt(0) for the DMA + everybody's rows landed
+    for (; tile < num_tiles; tile += (int)gridDim.x, buf ^= 1) {
+      const int ntile = tile + (int)gridDim.x;
+      if (ntile < num_tiles) issue_tile(ntile, buf ^ 1);
+
+      f32x4 acc[NPT][CTW];
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) acc[pt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const uint4* sx = &s_x[buf][0];
+      const int bunit = lg * GK_TP + li;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        if (q < nq) {
+#pragma unroll
+          for (int pt = 0; pt < NPT; ++pt) {
+            const bf16x8 bh = *(const bf16x8*)&sx[(q * 4) * GK_TP + bunit + pt * 16];
+            if (PROD == 3) {
+              const bf16x8 bl = *(const bf16x8*)&sx[((NQ + q) * 4) * GK_TP + bunit + pt * 16];
+#pragma unroll
+              for (int c = 0; c < CTW; ++c) acc[pt][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[c][q][1], bh, acc[pt][c], 0, 0, 0);
+#pragma unroll
+              for (int c = 0; c < CTW; ++c) acc[pt][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[c][q][0], bl, acc[pt][c], 0, 0, 0);
+            }
+#pragma unroll
+            for (int c = 0; c < CTW; ++c) acc[pt][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[c][q][0], bh, acc[pt][c], 0, 0, 0);
+          }
+        }
+      }
+
+      __syncthreads();  // next tile's rows have landed (vmcnt(0) also retires the PREVIOUS tile's stores, long done); all waves are done with this buffer
+      // ---- epilogue of this tile AFTER the barrier, so that its stores are in flight under the next tile's DMA and MFMAs instead
+      //      of being drained by this barrier's vmcnt(0): lane owns channels c0..c0+3 of pixel pix0 + 16*pt + li ----
+      {
+        const int n = tile / tiles_img;
+        const int64_t pix0 = (int64_t)(tile - n * tiles_img) * GK_TP;
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) {
+          const int cbase = ctg[c] * 16;
+          if (ctg[c] >= ct_total || cbase >= cout8) continue;
+          const int c0 = cbase + lg * 4;
+          if (c0 >= cout8) continue;
+          f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+          if (p.bias != nullptr) bias = ((const f32x4*)p.bias)[c0 >> 2];
+          f32x4 slope = {0.f, 0.f, 0.f, 0.f};
+          if (p.act == RSA_ACT_PRELU) slope = ((const f32x4*)p.act_vec)[c0 >> 2];
+          const bool has_f32grp = c0 < (p4 << 2);
+          const int64_t f32row = ((int64_t)n * p4 + (c0 >> 2)) * HW;
+          const int64_t outrow = (int64_t)n * p.out_batch_stride + (int64_t)(p.out_plane_off + (c0 >> 3)) * p.out_plane_stride;
+#pragma unroll
+          for (int pt = 0; pt < NPT; ++pt) {
+            const int64_t pix = pix0 + pt * 16 + li;
+            if (pix >= HW) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[pt][c][r] + bias[r];
+            if (p.act == RSA_ACT_SPAB_GATE) {
+              f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+              if (has_f32grp) rr = ((const f32x4*)p.res1)[f32row + pix];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = (v[r] + rr[r]) * (1.f / (1.f + expf(-v[r])) - 0.5f);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act, p.act == RSA_ACT_PRELU ? slope[r] : p.act_param);
+              if (p.res1 != nullptr && has_f32grp) {
+                const f32x4 rr = ((const f32x4*)p.res1)[f32row + pix];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + rr[r];
+              }
+            }
+            if (p.res2 != nullptr && has_f32grp) {
+              const f32x4 rr = ((const f32x4*)p.res2)[f32row + pix];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = v[r] * p.beta + rr[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (c0 + r >= p.cout) v[r] = 0.f;
+            if (p.out_hi != nullptr) {
+              uint32_t h0, l0, h1, l1;
+              split2(v[0], v[1], h0, l0);
+              split2(v[2], v[3], h1, l1);
+              const int64_t off = (outrow + pix) * 16 + (lg & 1) * 8;
+              *(uint2*)((char*)p.out_hi + off) = make_uint2(h0, h1);
+              if (p.out_lo != nullptr) *(uint2*)((char*)p.out_lo + off) = make_uint2(l0, l1);
+            }
+            if (p.out_f32 != nullptr && has_f32grp) ((f32x4*)p.out_f32)[f32row + pix] = (f32x4){v[0], v[1], v[2], v[3]};
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int PROD, int CTW, int NQ, int GK_TP>
+static int launch_gemm(const rsa_conv_params& p, hipStream_t stream) {
+  const int64_t HW = (int64_t)p.H * p.W;
+  const int64_t num_tiles = ((HW + GK_TP - 1) / GK_TP) * p.batch;
+  if (num_tiles > 0x7fffffff) return RSA_E_UNSUPPORTED;
+  static int resident = 0;
+  if (resident == 0) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_k1_kernel<PROD, CTW, NQ, GK_TP>, GK_WAVES * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipGetLastError();
+    resident = per_cu * prop.multiProcessorCount;
+  }
+  int gx = resident;
+  if (gx > num_tiles) gx = (int)num_tiles;
+  hipLaunchKernelGGL((gemm_k1_kernel<PROD, CTW, NQ, GK_TP>), dim3((unsigned)gx), dim3(GK_WAVES * 64), 0, stream, p);
+  return (int)hipGetLastError();
+}
+
+// Returns -100 when the layer is not a fit for this schedule (caller falls back to the halo-tile kernels).
+int gemm_k1_launch(const rsa_conv_params& p, hipStream_t stream) {
+  if (p.ksize != 1 || p.out_nchw != nullptr || p.upsample2x) return -100;
+  if (p.cout < 96) return -100;  // too few cout tiles to occupy 8 waves
+  const int nq = (p.cin_planes + 3) / 4;
+  if (p.products == 3) {
+    if (nq <= 8) return launch_gemm<3, 2, 8, 64>(p, stream);
+    if (nq <= 16) return launch_gemm<3, 1, 16, 32>(p, stream);
+  } else {
+    if (nq <= 16) return launch_gemm<1, 2, 16, 64>(p, stream);
+  }
+  return -100;
+}
+
+}  // namespace rsa
