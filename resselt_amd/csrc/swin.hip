@@ -29,115 +29,127 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
-// One wave = 16 consecutive tokens; lane l = (token l & 15, channel quarter l >> 4).  Each lane keeps its share of the token's
-// channels in registers (up to LN_MAXG float4 groups), so the f32 map is read from HBM exactly ONCE: mean and the centred
-// variance are two in-register passes, each closed by two xor-shuffles across the 4 lanes of a token.  Lanes 0-15 of a load
-// touch 16 consecutive tokens of one channel group = one 256-byte run.
-constexpr int LN_MAXG = 16;  // float4 groups per lane: supports C <= 4 * 4 * 16 = 256 channels in registers
+// One workgroup (4 waves) = 64 consecutive tokens; lane = token, wave w owns channel planes w, w+4, w+8, ...  Every load
+// and store instruction of a wave is then 64 consecutive tokens of one plane = 1 KiB contiguous in HBM.  A wave keeps its
+// planes in registers (up to LN_MAXP planes = 8*4*LN_MAXP = 256 channels), so the f32 map is read exactly once; mean and the
+// centred variance are each closed by a 4-way reduction through LDS.
+constexpr int LN_MAXP = 8;
 
 template <bool IN_REGS>
 __global__ __launch_bounds__(256) void layernorm_kernel(const rsa_layernorm_params p) {
+  __shared__ float s_red[2][4][64];
   const int64_t HW = (int64_t)p.H * p.W;
   const int64_t total = (int64_t)p.batch * HW;
   const int p4 = (p.C + 3) >> 2;
   const int planes = (p.C + 7) >> 3;
   const float inv_c = 1.f / (float)p.C;
   const int lane = threadIdx.x & 63;
-  const int tq = lane >> 4;  // channel quarter
-  const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  // groups g = tq, tq+4, tq+8, ... belong to this lane (plane pl = g >> 1: a lane pair (tq, tq^1) shares a plane)
-  for (int64_t base = wave_id * 16; base < total; base += nwaves * 16) {
-    const int64_t idx = base + (lane & 15);
+  const int wave = threadIdx.x >> 6;
+  const int64_t nblk = (total + 63) >> 6;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t idx = blk * 64 + lane;
     const bool live = idx < total;
     const int64_t pix = live ? idx % HW : 0;
     const int n = live ? (int)(idx / HW) : 0;
     const f32x4* x = (const f32x4*)p.x_f32 + (int64_t)n * p4 * HW + pix;
-    f32x4 v[LN_MAXG];
+    f32x4 v[LN_MAXP][2];
     float sum = 0.f;
+    if (IN_REGS) {
 #pragma unroll
-    for (int k = 0; k < LN_MAXG; ++k) {
-      const int g = tq + 4 * k;
-      v[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (IN_REGS && g < p4) v[k] = x[(int64_t)g * HW];
-      if (IN_REGS) {
+      for (int k = 0; k < LN_MAXP; ++k)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (g * 4 + r < p.C) sum += v[k][r];
-      }
+        for (int h = 0; h < 2; ++h) {
+          const int g = (wave + 4 * k) * 2 + h;
+          v[k][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (g < p4) v[k][h] = x[(int64_t)g * HW];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (g * 4 + r < p.C) sum += v[k][h][r];
+        }
+    } else {
+      for (int pl = wave; pl < planes; pl += 4)
+        for (int h = 0; h < 2; ++h) {
+          const int g = pl * 2 + h;
+          if (g >= p4) continue;
+          const f32x4 t = x[(int64_t)g * HW];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (g * 4 + r < p.C) sum += t[r];
+        }
     }
-    if (!IN_REGS) {
-      for (int g = tq; g < p4; g += 4) {
-        const f32x4 t = x[(int64_t)g * HW];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (g * 4 + r < p.C) sum += t[r];
-      }
-    }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    const float mean = sum * inv_c;
+    s_red[0][wave][lane] = sum;
+    __syncthreads();
+    const float mean = (s_red[0][0][lane] + s_red[0][1][lane] + s_red[0][2][lane] + s_red[0][3][lane]) * inv_c;
     float var = 0.f;
     if (IN_REGS) {
 #pragma unroll
-      for (int k = 0; k < LN_MAXG; ++k) {
-        const int g = tq + 4 * k;
+      for (int k = 0; k < LN_MAXP; ++k)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (g * 4 + r < p.C) {
-            const float d = v[k][r] - mean;
-            var += d * d;
-          }
-      }
-    } else {
-      for (int g = tq; g < p4; g += 4) {
-        const f32x4 t = x[(int64_t)g * HW];
+        for (int h = 0; h < 2; ++h) {
+          const int g = (wave + 4 * k) * 2 + h;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (g * 4 + r < p.C) {
-            const float d = t[r] - mean;
-            var += d * d;
-          }
-      }
-    }
-    var += __shfl_xor(var, 16);
-    var += __shfl_xor(var, 32);
-    const float rstd = rsqrtf(var * inv_c + p.eps);
-    if (!live) continue;
-    // normalise this lane's groups; group g covers channels 4g..4g+3 = half (g & 1) of plane g >> 1
-    auto emit = [&](int g, const f32x4 t) {
-      float y[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = g * 4 + r;
-        y[r] = (c < p.C) ? (t[r] - mean) * rstd * p.gamma[c] + p.beta[c] : 0.f;
-      }
-      if (p.out_f32 != nullptr && g < p4) ((f32x4*)p.out_f32)[((int64_t)n * p4 + g) * HW + pix] = (f32x4){y[0], y[1], y[2], y[3]};
-      if (p.out_hi != nullptr && (g >> 1) < planes) {
-        bf16x4 h, l;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const __bf16 hb = (__bf16)y[r];
-          h[r] = hb;
-          l[r] = (__bf16)(y[r] - (float)hb);
+          for (int r = 0; r < 4; ++r)
+            if (g * 4 + r < p.C) {
+              const float d = v[k][h][r] - mean;
+              var += d * d;
+            }
         }
-        const int64_t off = (((int64_t)n * p.out_batch_stride + (int64_t)(g >> 1) * p.out_plane_stride + pix) * 16) + (g & 1) * 8;
-        *(bf16x4*)((char*)p.out_hi + off) = h;
-        if (p.out_lo != nullptr) *(bf16x4*)((char*)p.out_lo + off) = l;
+    } else {
+      for (int pl = wave; pl < planes; pl += 4)
+        for (int h = 0; h < 2; ++h) {
+          const int g = pl * 2 + h;
+          if (g >= p4) continue;
+          const f32x4 t = x[(int64_t)g * HW];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (g * 4 + r < p.C) {
+              const float d = t[r] - mean;
+              var += d * d;
+            }
+        }
+    }
+    s_red[1][wave][lane] = var;
+    __syncthreads();  // also orders the next iteration's s_red[0] writes after this iteration's reads
+    const float rstd = rsqrtf((s_red[1][0][lane] + s_red[1][1][lane] + s_red[1][2][lane] + s_red[1][3][lane]) * inv_c + p.eps);
+    auto emit = [&](int pl, const f32x4 a, const f32x4 b) {
+      float y[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = pl * 8 + j;
+        const float t = j < 4 ? a[j] : b[j - 4];
+        y[j] = (c < p.C) ? (t - mean) * rstd * p.gamma[c] + p.beta[c] : 0.f;
+      }
+      if (p.out_f32 != nullptr) {
+        if (pl * 2 < p4) ((f32x4*)p.out_f32)[((int64_t)n * p4 + pl * 2) * HW + pix] = (f32x4){y[0], y[1], y[2], y[3]};
+        if (pl * 2 + 1 < p4) ((f32x4*)p.out_f32)[((int64_t)n * p4 + pl * 2 + 1) * HW + pix] = (f32x4){y[4], y[5], y[6], y[7]};
+      }
+      if (p.out_hi != nullptr) {
+        bf16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const __bf16 hb = (__bf16)y[j];
+          h[j] = hb;
+          l[j] = (__bf16)(y[j] - (float)hb);
+        }
+        const int64_t unit = (int64_t)n * p.out_batch_stride + (int64_t)pl * p.out_plane_stride + pix;
+        ((bf16x8*)p.out_hi)[unit] = h;
+        if (p.out_lo != nullptr) ((bf16x8*)p.out_lo)[unit] = l;
       }
     };
-    const int g_end = planes * 2;  // groups up to the end of the last plane (a trailing half plane is written as zeros)
-    if (IN_REGS) {
+    if (live) {
+      if (IN_REGS) {
 #pragma unroll
-      for (int k = 0; k < LN_MAXG; ++k) {
-        const int g = tq + 4 * k;
-        if (g < g_end) emit(g, v[k]);
-      }
-    } else {
-      for (int g = tq; g < g_end; g += 4) {
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if (g < p4) t = x[(int64_t)g * HW];
-        emit(g, t);
+        for (int k = 0; k < LN_MAXP; ++k) {
+          const int pl = wave + 4 * k;
+          if (pl < planes) emit(pl, v[k][0], v[k][1]);
+        }
+      } else {
+        for (int pl = wave; pl < planes; pl += 4) {
+          f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+          if (pl * 2 < p4) a = x[(int64_t)(pl * 2) * HW];
+          if (pl * 2 + 1 < p4) b = x[(int64_t)(pl * 2 + 1) * HW];
+          emit(pl, a, b);
+        }
       }
     }
   }
@@ -370,9 +382,9 @@ extern "C" int rsa_layernorm(const rsa_layernorm_params* p, void* stream) {
   if (((uintptr_t)p->x_f32 | (uintptr_t)p->out_hi | (uintptr_t)p->out_lo | (uintptr_t)p->out_f32) & 15)
     return set_error(RSA_E_ALIGN, "layernorm: maps must be 16-byte aligned");
   const int64_t total = (int64_t)p->batch * p->H * p->W;
-  int64_t g = (total + 63) / 64;  // 4 waves of 16 tokens per 256-thread workgroup
+  int64_t g = (total + 63) / 64;  // one 256-thread workgroup per 64 tokens
   if (g > 256 * 32) g = 256 * 32;
-  if (p->C <= 16 * LN_MAXG)
+  if (p->C <= 32 * LN_MAXP)
     hipLaunchKernelGGL(layernorm_kernel<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, *p);
   else
     hipLaunchKernelGGL(layernorm_kernel<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, *p);
