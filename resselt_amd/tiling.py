@@ -140,7 +140,7 @@ class TileParallel:
         mh = max(t.shape[0] for t in tiles) * s
         mw = max(t.shape[1] for t in tiles) * s
         per_rank = -(-len(tiles) // world)
-        c_out, dtype, device = self._out_meta(ref, x, outs)
+        c_out, dtype, device = self._out_meta(ref, x, idle_ranks=len(tiles) < world)
         send = torch.zeros((per_rank, n, c_out, mh, mw), dtype=dtype, device=device)
         for k, (t, o) in enumerate(zip(mine, outs)):
             if o.numel():
@@ -155,12 +155,15 @@ class TileParallel:
             full[:, :, t.y0 * s : t.y1 * s, t.x0 * s : t.x1 * s] = recv[r, k, :, :, : th * s, : tw * s]
         return full
 
-    def _out_meta(self, ref, x, outs):
+    def _out_meta(self, ref, x, idle_ranks: bool):
+        """(channels, dtype, device) of the output tiles.  Only when there are fewer tiles than ranks can a rank have no
+        output of its own; ``idle_ranks`` is the same on every rank, so all of them enter the exchange together."""
         import torch.distributed as dist
 
-        if ref is not None:
+        if not idle_ranks:
             return ref.shape[1], ref.dtype, ref.device
-        # a rank without work still has to join the collective with the right shape: ask rank 0
-        meta = [None]
-        dist.broadcast_object_list(meta, src=0, group=self.group)
-        return meta[0]
+        mine = None if ref is None else (ref.shape[1], ref.dtype)
+        metas = [None] * dist.get_world_size(self.group)
+        dist.all_gather_object(metas, mine, group=self.group)
+        c_out, dtype = next(m for m in metas if m is not None)
+        return c_out, dtype, (ref.device if ref is not None else x.device)

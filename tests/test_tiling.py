@@ -66,7 +66,8 @@ def _worker(rank, world, port, q):
         x = synth.synth_input((1, 3, 40, 52), seed=9)  # every rank builds the same input
         y = TileParallel(model, scale=2, halo=24)(x)
         y3 = TileParallel(model, scale=2, halo=24, grid=(3, 1))(x)  # 3 uneven tiles on 2 ranks: round-robin + padding
-        q.put((rank, y, y3))
+        y1 = TileParallel(model, scale=2, halo=24, grid=(1, 1))(x)  # fewer tiles than ranks: rank 1 idles but joins the collective
+        q.put((rank, y, y3, y1))
     finally:
         dist.destroy_process_group()
 
@@ -83,15 +84,16 @@ def test_two_rank_tile_parallel_all_gather_gloo():
         p.start()
     results = dict()
     for _ in range(2):
-        rank, y, y3 = q.get(timeout=120)
-        results[rank] = (y.clone(), y3.clone())
+        rank, y, y3, y1 = q.get(timeout=120)
+        results[rank] = (y.clone(), y3.clone(), y1.clone())
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     model = _model()
     full = model(synth.synth_input((1, 3, 40, 52), seed=9))
     for rank in (0, 1):
-        y, y3 = results[rank]
+        y, y3, y1 = results[rank]
         assert y.shape == full.shape
         assert (y - full).abs().max().item() <= 1e-6, rank  # every rank ends with the whole image
         assert (y3 - full).abs().max().item() <= 1e-6, rank
+        assert (y1 - full).abs().max().item() <= 1e-6, rank
