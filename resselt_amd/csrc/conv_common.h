@@ -1,4 +1,4 @@
-// conv_common.h — pieces shared by the two schedules of the fused convolution (conv_mfma.hip, conv_rs.hip):
+// conv_common.h — pieces shared by the fused-convolution schedules (conv_mfma.hip, gemm_k1.hip):
 // vector types, activation functions, the bf16 hi/lo split and the tile epilogue.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -16,26 +16,57 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 constexpr int NPL = 4;  // planes per K chunk (32 channels = one MFMA K)
 
+// Activation CLASS of an epilogue instantiation.  The epilogue is compiled once per class and selected by ONE wave-uniform
+// switch per tile: with a per-value runtime switch every one of the 64 value sites of the unrolled epilogue carried the inlined
+// libm code of Mish/GELU/SiLU (24k ISA lines per kernel), and each tile streamed ~200 KB of instructions through the 64 KB
+// instruction cache even when only LeakyReLU ran (profiles/r01_l_ab_epilogue.txt).
+enum { AC_LINEAR = 0 /* none, LeakyReLU, PReLU */, AC_MISH = 1, AC_SILU = 2, AC_GELU = 3, AC_GATE = 4 };
+
+template <int AC>
 __device__ __forceinline__ float act_apply(float v, int act, float prm) {
+  if (AC == AC_LINEAR) {  // prm = LeakyReLU slope or this channel's PReLU slope
+    return (act == RSA_ACT_NONE || v >= 0.f) ? v : v * prm;
+  } else if (AC == AC_MISH) {
+    // torch: x * tanh(softplus(x)) with softplus threshold 20.  tanh(ln(1+n)) = (n^2+2n)/(n^2+2n+2) for n = e^x, so one exp and
+    // one division replace log1p + tanh (exact algebra; keeps the unrolled epilogue small enough for the instruction cache)
+    if (v > 20.f) return v;  // tanh(x) == 1.0f in f32 from x = 9.02 on
+    const float n = expf(v);
+    const float t = n * (n + 2.f);
+    return v * (t / (t + 2.f));
+  } else if (AC == AC_SILU) {
+    return v / (1.f + expf(-v));
+  } else if (AC == AC_GELU) {
+    return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+  }
+  return v;
+}
+
+__device__ __forceinline__ int act_class(int act) {
   switch (act) {
-    case RSA_ACT_LRELU:
-    case RSA_ACT_PRELU:  // prm = this channel's slope
-      return v >= 0.f ? v : v * prm;
-    case RSA_ACT_MISH: {
-      // torch: x * tanh(softplus(x)), softplus threshold 20
-      float sp = v > 20.f ? v : log1pf(expf(v));
-      return v * tanhf(sp);
-    }
+    case RSA_ACT_MISH:
+      return AC_MISH;
     case RSA_ACT_SILU:
-      return v / (1.f + expf(-v));
+      return AC_SILU;
     case RSA_ACT_GELU:
-      return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+      return AC_GELU;
+    case RSA_ACT_SPAB_GATE:
+      return AC_GATE;
     default:
-      return v;
+      return AC_LINEAR;
   }
 }
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+// Workgroup barrier WITHOUT the vmcnt(0) drain that __syncthreads() carries: only this wave's LDS traffic is waited for, so
+// weight prefetches and epilogue stores stay in flight across it.  A wave whose LDS-DMA must have landed calls dma_wait() first.
+__device__ __forceinline__ void wg_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // (a, b) -> packed bf16 pair (RNE) and the pair's rounding residuals, also packed
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
@@ -72,9 +103,18 @@ struct GeoLW {
 //   c0 = 16*(slab*NCT + CTW*wct + c) + 4*lg .. +3  of pixel (y0 + 4*wpx + (pt>>1), x0 + 16*(pt&1) + li).
 // OUTK = 0: split planes and/or f32 residual map (with activation / residual epilogues)
 // OUTK = 1: final plain NCHW tensor (optional activation, depth-to-space and affine), any dtype
-template <int NCT, int CTW, int OUTK>
-__device__ __forceinline__ void epilogue(const rsa_conv_params& p, const f32x4 (&acc)[8][CTW], int n, int y0, int x0, int slab, int wct, int wpx,
-                                         int li, int lg) {
+template <int NCT, int CTW, int OUTK, int AC>
+__device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f32x4 (&acc)[8][CTW], int n, int y0, int x0, int slab, int wct,
+                                              int wpx, int li, int lg) {
+#ifdef RSA_ABL_NOEPI
+  if (p.H > 0) {  // timing-only build: no epilogue, but every accumulator stays live (no dead-code elimination of the MFMAs)
+#pragma unroll
+    for (int pt = 0; pt < 8; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < CTW; ++ct) asm volatile("" ::"v"(acc[pt][ct]));
+    return;
+  }
+#endif
   const int64_t HW = (int64_t)p.H * p.W;
   const int64_t pix0 = (int64_t)y0 * p.W + x0;  // uniform
   const int p4 = (p.cout + 3) >> 2;
@@ -90,16 +130,28 @@ __device__ __forceinline__ void epilogue(const rsa_conv_params& p, const f32x4 (
     pvalid[pt] = (y0 + ry < p.H) && (x0 + rx < p.W);
   }
 
+  // vmcnt retires IN ORDER and counts stores: a load issued after a store cannot be waited for before that store's write is
+  // acknowledged.  So every load of the epilogue is issued ahead of the stores it would otherwise queue behind: bias / slope
+  // vectors of all cout tiles here, each cout tile's residual fragments before that tile's first store.
+  f32x4 biasv[CTW], slopev[CTW];
+#pragma unroll
+  for (int ct = 0; ct < CTW; ++ct) {
+    const int c0 = (ctile0 + ct) * 16 + lg * 4;
+    const bool live = (wct * CTW + ct < NCT) && c0 < cout8;
+    biasv[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    slopev[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr && live) biasv[ct] = ((const f32x4*)p.bias)[c0 >> 2];  // bias is padded to a multiple of 16
+    if (p.act == RSA_ACT_PRELU && live) slopev[ct] = ((const f32x4*)p.act_vec)[c0 >> 2];  // per-channel PReLU slopes, same padding
+  }
+
 #pragma unroll
   for (int ct = 0; ct < CTW; ++ct) {
     if (wct * CTW + ct >= NCT) break;
     const int cbase = (ctile0 + ct) * 16;  // uniform
     if (cbase >= cout8) break;
     const int c0 = cbase + lg * 4;
-    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr) bias = ((const f32x4*)p.bias)[c0 >> 2];  // bias is padded to a multiple of 16
-    f32x4 slope = {0.f, 0.f, 0.f, 0.f};
-    if (p.act == RSA_ACT_PRELU) slope = ((const f32x4*)p.act_vec)[c0 >> 2];  // per-channel PReLU slopes, same padding
+    const f32x4 bias = biasv[ct];
+    const f32x4 slope = slopev[ct];
     const bool cvalid = c0 < cout8;
     const bool has_f32grp = c0 < (p4 << 2);
     // uniform bases for this cout tile
@@ -111,91 +163,143 @@ __device__ __forceinline__ void epilogue(const rsa_conv_params& p, const f32x4 (
     char* olb = (char*)p.out_lo + ounit0 * 16;
     const uint32_t f32lane = (uint32_t)lg * (uint32_t)HW;                       // + lpix, in float4 units
     const uint32_t pllane = (uint32_t)(lg >> 1) * (uint32_t)p.out_plane_stride;  // + lpix, in 16-byte units
+    // pixel tiles are handled in PAIRS (2k, 2k+1) = the two 16-pixel halves of one row.  After the per-fragment math the two
+    // lanes that hold the two halves of a 16-byte unit (lg, lg^1 = lanes l, l^16) exchange one half each, so that lane lg-even
+    // stores the FULL unit of pixel-tile 2k and lane lg-odd the full unit of pixel-tile 2k+1: 16-byte stores, 512 contiguous
+    // bytes per plane and instruction instead of two half-filled 256-byte runs (the 8-byte form was store-issue bound:
+    // profiles/r01_l_ab_epilogue.txt)
 #pragma unroll
-    for (int pt = 0; pt < 8; ++pt) {
-      if (!pvalid[pt] || !cvalid) continue;
-      float v[4];
+    for (int pp = 0; pp < 4; ++pp) {
+      float v[2][4];
+      bool ok[2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[pt][ct][r] + bias[r];
-      if (OUTK == 0) {
-        const uint32_t foff = (f32lane + lpix[pt]) * 16u;
-        if (p.act == RSA_ACT_SPAB_GATE) {
-          f32x4 rr = {0.f, 0.f, 0.f, 0.f};
-          if (has_f32grp) rr = *(const f32x4*)(r1b + foff);
+      for (int e = 0; e < 2; ++e) {
+        const int pt = pp * 2 + e;
+        ok[e] = pvalid[pt] && cvalid;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float sg = 1.f / (1.f + expf(-v[r]));
-            v[r] = (v[r] + rr[r]) * (sg - 0.5f);
+        for (int r = 0; r < 4; ++r) v[e][r] = acc[pt][ct][r] + bias[r];
+        if (OUTK == 0) {
+          const uint32_t foff = (f32lane + lpix[pt]) * 16u;
+          if (AC == AC_GATE) {
+            f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+            if (ok[e] && has_f32grp) rr = *(const f32x4*)(r1b + foff);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float sg = 1.f / (1.f + expf(-v[e][r]));
+              v[e][r] = (v[e][r] + rr[r]) * (sg - 0.5f);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[e][r] = act_apply<AC>(v[e][r], p.act, p.act == RSA_ACT_PRELU ? slope[r] : p.act_param);
+            if (p.res1 != nullptr && has_f32grp && ok[e]) {
+              const f32x4 rr = *(const f32x4*)(r1b + foff);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[e][r] = v[e][r] * p.alpha + rr[r];
+            }
           }
-        } else {
+          if (p.res2 != nullptr && has_f32grp && ok[e]) {
+            const f32x4 rr = *(const f32x4*)(r2b + foff);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act, p.act == RSA_ACT_PRELU ? slope[r] : p.act_param);
-          if (p.res1 != nullptr && has_f32grp) {
-            const f32x4 rr = *(const f32x4*)(r1b + foff);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + rr[r];
+            for (int r = 0; r < 4; ++r) v[e][r] = v[e][r] * p.beta + rr[r];
           }
-        }
-        if (p.res2 != nullptr && has_f32grp) {
-          const f32x4 rr = *(const f32x4*)(r2b + foff);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = v[r] * p.beta + rr[r];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (c0 + r >= p.cout) v[r] = 0.f;
-        if (p.out_hi != nullptr) {
-          uint32_t h0, l0, h1, l1;
-          split2(v[0], v[1], h0, l0);
-          split2(v[2], v[3], h1, l1);
-          const uint32_t uoff = (pllane + lpix[pt]) * 16u + (uint32_t)(lg & 1) * 8u;
-          *(uint2*)(ohb + uoff) = make_uint2(h0, h1);
-          if (p.out_lo != nullptr) *(uint2*)(olb + uoff) = make_uint2(l0, l1);
-        }
-        if (p.out_f32 != nullptr && has_f32grp) *(f32x4*)(f32b + foff) = (f32x4){v[0], v[1], v[2], v[3]};
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act, p.act == RSA_ACT_PRELU ? slope[r] : p.act_param);
-        const int ps = p.pixel_shuffle > 1 ? p.pixel_shuffle : 1;
-        const int oc_total = p.cout / (ps * ps);
-        const int64_t oW = (int64_t)p.W * ps;
-        const int64_t oHW = (int64_t)p.H * ps * oW;
-        const int y = y0 + wpx * 4 + (pt >> 1), x = x0 + (pt & 1) * 16 + li;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = c0 + r;
-          if (c >= p.cout) continue;
-          const int oc = c / (ps * ps);
-          const int rem = c - oc * ps * ps;
-          const int ii = rem / ps;
-          const int jj = rem - ii * ps;
-          float o = v[r] * p.out_scale;
-          if (p.out_shift != nullptr) o += p.out_shift[oc];
-          if (p.out_base != nullptr) {  // nearest-upsampled base image: the low-resolution pixel this output pixel sits in
-            const int64_t bi = (((int64_t)n * oc_total + oc) * p.H + y) * p.W + x;
-            if (p.out_dtype == RSA_F32)
-              o += ((const float*)p.out_base)[bi];
-            else if (p.out_dtype == RSA_F16)
-              o += (float)((const _Float16*)p.out_base)[bi];
-            else
-              o += (float)((const __bf16*)p.out_base)[bi];
-          }
-          const int64_t idx = ((int64_t)n * oc_total + oc) * oHW + ((int64_t)y * ps + ii) * oW + ((int64_t)x * ps + jj);
-          if (p.out_dtype == RSA_F32)
-            ((float*)p.out_nchw)[idx] = o;
-          else if (p.out_dtype == RSA_F16)
-            ((_Float16*)p.out_nchw)[idx] = (_Float16)o;
-          else
-            ((__bf16*)p.out_nchw)[idx] = (__bf16)o;
+          for (int r = 0; r < 4; ++r)
+            if (c0 + r >= p.cout) v[e][r] = 0.f;
+          if (p.out_f32 != nullptr && has_f32grp && ok[e]) *(f32x4*)(f32b + foff) = (f32x4){v[e][0], v[e][1], v[e][2], v[e][3]};
         }
       }
-      // keep the 8*CTW fragment epilogues from being interleaved by the scheduler: interleaving them costs more registers
-      // than the 168-VGPR budget of the 9-wave schedule has and turns the epilogue into scratch traffic
-      // (in-process A/B, profiles/r01_h_ab_epilogue_serial.txt: +2..4 % on bf16x3 layers)
+      if (OUTK == 0) {
+        if (p.out_hi != nullptr) {  // wave-uniform: every lane takes part in the exchange
+          uint32_t h[2][2], l[2][2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            split2(v[e][0], v[e][1], h[e][0], l[e][0]);
+            split2(v[e][2], v[e][3], h[e][1], l[e][1]);
+          }
+          const int odd = lg & 1;  // odd lanes keep pixel-tile 2k+1 and give away their half of 2k; even lanes the reverse
+          uint32_t sh[2], sl[2], rh[2], rl[2];
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            sh[d] = odd ? h[0][d] : h[1][d];
+            sl[d] = odd ? l[0][d] : l[1][d];
+            rh[d] = (uint32_t)__shfl_xor((int)sh[d], 16);
+            rl[d] = (uint32_t)__shfl_xor((int)sl[d], 16);
+          }
+          const int pt = pp * 2 + odd;
+          // unit = channels 8*(plane) .. +7: the even lane owns channels 0-3, the odd lane channels 4-7
+          const uint4 uh = odd ? make_uint4(rh[0], rh[1], h[1][0], h[1][1]) : make_uint4(h[0][0], h[0][1], rh[0], rh[1]);
+          const uint4 ul = odd ? make_uint4(rl[0], rl[1], l[1][0], l[1][1]) : make_uint4(l[0][0], l[0][1], rl[0], rl[1]);
+          // the partner lane has the same pixel column li and the same plane; both halves are valid together (same cvalid)
+          if (pvalid[pt] && cvalid) {
+            const uint32_t uoff = (pllane + lpix[pt]) * 16u;
+            *(uint4*)(ohb + uoff) = uh;
+            if (p.out_lo != nullptr) *(uint4*)(olb + uoff) = ul;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int pt = pp * 2 + e;
+          if (!ok[e]) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[e][r] = act_apply<AC>(v[e][r], p.act, p.act == RSA_ACT_PRELU ? slope[r] : p.act_param);
+          const int ps = p.pixel_shuffle > 1 ? p.pixel_shuffle : 1;
+          const int oc_total = p.cout / (ps * ps);
+          const int64_t oW = (int64_t)p.W * ps;
+          const int64_t oHW = (int64_t)p.H * ps * oW;
+          const int y = y0 + wpx * 4 + (pt >> 1), x = x0 + (pt & 1) * 16 + li;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = c0 + r;
+            if (c >= p.cout) continue;
+            const int oc = c / (ps * ps);
+            const int rem = c - oc * ps * ps;
+            const int ii = rem / ps;
+            const int jj = rem - ii * ps;
+            float o = v[e][r] * p.out_scale;
+            if (p.out_shift != nullptr) o += p.out_shift[oc];
+            if (p.out_base != nullptr) {  // nearest-upsampled base image: the low-resolution pixel this output pixel sits in
+              const int64_t bi = (((int64_t)n * oc_total + oc) * p.H + y) * p.W + x;
+              if (p.out_dtype == RSA_F32)
+                o += ((const float*)p.out_base)[bi];
+              else if (p.out_dtype == RSA_F16)
+                o += (float)((const _Float16*)p.out_base)[bi];
+              else
+                o += (float)((const __bf16*)p.out_base)[bi];
+            }
+            const int64_t idx = ((int64_t)n * oc_total + oc) * oHW + ((int64_t)y * ps + ii) * oW + ((int64_t)x * ps + jj);
+            if (p.out_dtype == RSA_F32)
+              ((float*)p.out_nchw)[idx] = o;
+            else if (p.out_dtype == RSA_F16)
+              ((_Float16*)p.out_nchw)[idx] = (_Float16)o;
+            else
+              ((__bf16*)p.out_nchw)[idx] = (__bf16)o;
+          }
+        }
+      }
+      // keep the fragment epilogues from being interleaved by the scheduler: interleaving them costs more registers than the
+      // 168-VGPR budget of the 9-wave schedule has and turns the epilogue into scratch traffic
       __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
 
+template <int NCT, int CTW, int OUTK>
+__device__ __forceinline__ void epilogue(const rsa_conv_params& p, const f32x4 (&acc)[8][CTW], int n, int y0, int x0, int slab, int wct, int wpx,
+                                         int li, int lg) {
+  switch (act_class(p.act)) {  // wave-uniform: one compact code path is fetched per tile
+    case AC_MISH:
+      return epilogue_impl<NCT, CTW, OUTK, AC_MISH>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
+    case AC_SILU:
+      return epilogue_impl<NCT, CTW, OUTK, AC_SILU>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
+    case AC_GELU:
+      return epilogue_impl<NCT, CTW, OUTK, AC_GELU>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
+    case AC_GATE:
+      if (OUTK == 0) return epilogue_impl<NCT, CTW, OUTK, AC_GATE>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
+      return;
+    default:
+      return epilogue_impl<NCT, CTW, OUTK, AC_LINEAR>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
+  }
+}
 
 }  // namespace rsa

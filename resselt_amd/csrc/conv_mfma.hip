@@ -101,7 +101,7 @@ __global__ __launch_bounds__((GeoLW<KS, NCT>::NTHR), (GeoLW<KS, NCT>::NCW == 8 ?
         continue;
 #endif
 #ifdef RSA_ABL_NODMA
-        if (k > 1) { __syncthreads(); continue; }
+        if (k > 1) { wg_barrier(); continue; }
 #endif
         const int planes_left = p.cin_planes - q * NPL;
         const uint4* ch = img_hi + (int64_t)q * NPL * p.in_plane_stride;
@@ -120,7 +120,8 @@ __global__ __launch_bounds__((GeoLW<KS, NCT>::NTHR), (GeoLW<KS, NCT>::NCW == 8 ?
                                              (__attribute__((address_space(3))) void*)(dst + ACT_UNITS + it * 64), 16, 0, 0);
           }
         }
-        __syncthreads();  // drains this wave's DMA (vmcnt(0)) and meets the compute waves: buffer (k & 1) is ready
+        dma_wait();    // this wave's DMA has landed ...
+        wg_barrier();  // ... and meets the compute waves: buffer (k & 1) is ready
       }
     }
     return;
@@ -174,7 +175,8 @@ __global__ __launch_bounds__((GeoLW<KS, NCT>::NTHR), (GeoLW<KS, NCT>::NCW == 8 ?
    for (int slab = 0; slab < nslabs; ++slab) {
     for (int q = 0; q < nchunks; ++q, ++k) {
 #ifndef RSA_ABL_NOBAR
-      __syncthreads();  // buffer (k & 1) has landed; everyone finished reading the other buffer one item ago
+      wg_barrier();  // buffer (k & 1) has landed; everyone finished reading the other buffer one item ago (weight prefetches and
+                     // the previous tile's stores stay in flight: no vmcnt drain here)
 #endif
       const uint4* sa = &s_act[k & 1][0];
 #ifdef RSA_ABL_NOMFMA
@@ -296,22 +298,8 @@ static int launch_one(const rsa_conv_params& p, hipStream_t stream) {
 
 int gemm_k1_launch(const rsa_conv_params& p, hipStream_t stream);  // gemm_k1.hip; -100 = not applicable
 
-// register-staged schedule (conv_rs.hip), explicitly instantiated there
-template <int KS, int NCT, int PROD, int UP, int OUTK>
-int launch_rs(const rsa_conv_params& p, hipStream_t stream);
-extern template int launch_rs<3, 1, 3, 0, 0>(const rsa_conv_params&, hipStream_t);
-extern template int launch_rs<3, 2, 3, 0, 0>(const rsa_conv_params&, hipStream_t);
-extern template int launch_rs<3, 1, 3, 1, 0>(const rsa_conv_params&, hipStream_t);
-extern template int launch_rs<3, 2, 3, 1, 0>(const rsa_conv_params&, hipStream_t);
-
 template <int KS, int PROD, int UP, int OUTK>
 static int launch_nct2(const rsa_conv_params& p, int nct, hipStream_t stream) {
-  // schedule choice (measured, profiles/r01_b_conv_microbench.txt): split-bf16 k3 layers with <= 2 cout tiles run faster as two
-  // independent register-staged workgroups per CU; everything else uses the loader-wave schedule below
-  if constexpr (KS == 3 && PROD == 3 && OUTK == 0) {
-    if (nct == 1) return launch_rs<3, 1, 3, UP, 0>(p, stream);
-    if (nct == 2) return launch_rs<3, 2, 3, UP, 0>(p, stream);
-  }
   switch (nct) {
     case 1:
       return launch_one<KS, 1, PROD, UP, OUTK>(p, stream);

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(GK_WAVES * 64, 2) void gemm_k1_kernel(const rsa_con
               for (int r = 0; r < 4; ++r) v[r] = (v[r] + rr[r]) * (1.f / (1.f + expf(-v[r])) - 0.5f);
             } else {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act, p.act == RSA_ACT_PRELU ? slope[r] : p.act_param);
+              for (int r = 0; r < 4; ++r) v[r] = (p.act == RSA_ACT_GELU) ? act_apply<AC_GELU>(v[r], p.act, 0.f) : act_apply<AC_LINEAR>(v[r], p.act, p.act == RSA_ACT_PRELU ? slope[r] : p.act_param);
               if (p.res1 != nullptr && has_f32grp) {
                 const f32x4 rr = ((const f32x4*)p.res1)[f32row + pix];
 #pragma unroll
@@ -215,6 +215,7 @@ static int launch_gemm(const rsa_conv_params& p, hipStream_t stream) {
 // Returns -100 when the layer is not a fit for this schedule (caller falls back to the halo-tile kernels).
 int gemm_k1_launch(const rsa_conv_params& p, hipStream_t stream) {
   if (p.ksize != 1 || p.out_nchw != nullptr || p.upsample2x) return -100;
+  if (p.act == RSA_ACT_MISH || p.act == RSA_ACT_SILU) return -100;  // only the linear class, GELU and the SPAB gate are compiled into this schedule
   if (p.cout < 96) return -100;  // too few cout tiles to occupy 8 waves
   const int nq = (p.cin_planes + 3) / 4;
   if (p.products == 3) {
