@@ -207,7 +207,7 @@ def main():
                 'frac': round(achieved_tf / MFMA_PEAK_TFLOPS, 4),
                 'traffic': traffic,
                 'traffic_unit': 'HBM bytes per launch (avg over the 351 conv launches), from ' + traffic_src if traffic else None,
-                'kernel': 'rsa::conv_kernel / conv_kernel_rs <KS,NCT,PROD,UP,OUTK> (all 351 conv launches of one forward)',
+                'kernel': 'rsa::conv_kernel<KS,NCT,PROD,UP,OUTK> (all 351 conv launches of one forward)',
                 'avg_launch_us': None if not n_launch else round(kern_s / n_launch * 1e6, 2),
                 'mfma_issued_frac': round(achieved_tf * (3 if args.precision == 'bf16x3' else 1) / MFMA_PEAK_TFLOPS, 4),
             },
