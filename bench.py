@@ -177,6 +177,7 @@ def main():
         flop = 2 * macs * H * W
         achieved_tf = flop / kern_s / 1e12
         achieved_gbs = HBM_B_PER_OUT_PX * out_px / kern_s / 1e9
+        layout_bytes = model.conv_bytes_per_forward()  # same layer-wise model, priced in this engine's split-plane/f32-map layouts
         traffic, traffic_src = measured_traffic() if (args.precision == 'bf16x3' and (H, W, args.blocks) == (1080, 1920, 23)) else (None, None)
         res = {
             'metric': 'output megapixels/sec, RealESRGAN-x4plus 1080p\u21924K, 1/2/4/8 MI355X',
@@ -218,6 +219,10 @@ def main():
                 'unit': 'GB/s',
                 'frac': round(achieved_gbs / HBM_PEAK_GBS, 4),
                 'model': 'layer-wise bf16 bytes, 7,790 B per output pixel (SURVEY.md 8d)',
+                'layout_bytes_per_launch': None if not layout_bytes else round(layout_bytes / n_launch),
+                'layout_achieved': None if not layout_bytes else round(layout_bytes / kern_s / 1e9, 1),
+                'layout_note': 'the same every-operand-once model priced in the engine layouts (hi+lo bf16 planes = 4 B/channel for 3 products, f32 residual maps); '
+                'compare roofline.traffic against layout_bytes_per_launch',
             },
             'event_ms_per_step': round(ev_ms / args.steps, 3),
         }

@@ -21,6 +21,22 @@ from .tensors import Planes, empty_f32map
 PRECISIONS = {'bf16x3': 3, 'bf16': 1}
 
 
+def conv_algorithmic_bytes(p: L.ConvParams) -> int:
+    """Bytes one launch must move if every operand is touched exactly once (no halo re-reads, weights excluded):
+    input planes (16-byte units of 8 bf16 channels, hi and -- for 3 products -- lo), f32 residual maps, and every output it writes."""
+    px_out = p.batch * p.H * p.W
+    px_in = px_out // 4 if p.upsample2x else px_out
+    total = p.cin_planes * 16 * (2 if p.products == 3 else 1) * px_in
+    maps = (p.cout + 3) // 4 * 16 * px_out
+    total += maps * sum(1 for r in (p.res1, p.res2, p.out_f32) if r)
+    if p.out_hi:
+        total += (p.cout + 7) // 8 * 16 * (2 if p.out_lo else 1) * px_out
+    if p.out_nchw:
+        esize = {L.F32: 4, L.F16: 2, L.BF16: 2}[p.out_dtype]
+        total += p.cout * esize * px_out * (2 if p.out_base else 1)
+    return total
+
+
 class Plan:
     """Buffers + launch list for one (batch, H, W, dtype, device, precision) signature."""
 
@@ -44,6 +60,7 @@ class Plan:
     # ---- launch list ----
     def conv(self, params: L.ConvParams) -> L.ConvParams:
         self._pending.append(params)
+        self._conv_bytes = getattr(self, '_conv_bytes', 0) + conv_algorithmic_bytes(params)
         return params
 
     def flush(self) -> 'C.Array | None':
@@ -68,6 +85,10 @@ class Plan:
 
     def n_launches(self) -> int:
         return getattr(self, '_n_launches', 0)
+
+    def conv_bytes(self) -> int:
+        """Algorithmic HBM bytes of the convolution launches in THIS engine's layouts (see ``conv_algorithmic_bytes``)."""
+        return getattr(self, '_conv_bytes', 0)
 
     def buffer_bytes(self) -> int:
         total = 0
@@ -112,6 +133,11 @@ class EngineModule(nn.Module):
         if not self._plans:
             return None
         return list(self._plans.values())[-1][0].n_launches()
+
+    def conv_bytes_per_forward(self) -> int | None:
+        if not self._plans:
+            return None
+        return list(self._plans.values())[-1][0].conv_bytes()
 
     @property
     def products(self) -> int:
