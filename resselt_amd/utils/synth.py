@@ -230,3 +230,139 @@ def compact_state_dict(num_in_ch=3, num_feat=64, num_conv=16, upscale=4, seed=0)
         cin = num_feat
     _conv(sd, f'body.{2 * (num_conv + 1)}', num_in_ch * upscale * upscale, num_feat, 3, seed)
     return sd
+
+
+def dat_geometry(split_size, idx: int):
+    """(H_sp, W_sp) of attention branch ``idx`` (archs/dat/arch.py:186-191): branch 1 swaps the rectangle."""
+    return (split_size[0], split_size[1]) if idx == 0 else (split_size[1], split_size[0])
+
+
+def dat_shifted(rg_idx: int, b_idx: int) -> bool:
+    """Which DATB blocks shift their windows (archs/dat/arch.py:312, 453)."""
+    return (rg_idx % 2 == 0 and b_idx > 0 and (b_idx - 2) % 4 == 0) or (rg_idx % 2 != 0 and b_idx % 4 == 0)
+
+
+def dat_shift_masks(H: int, W: int, split_size, shift_size):
+    """The two additive shift masks [nW, N, N] (archs/dat/arch.py:336-411), one per branch."""
+    out = []
+    for idx in (0, 1):
+        hs, ws = dat_geometry(split_size, idx)
+        sh, sw = dat_geometry(shift_size, idx)
+        img = torch.zeros(H, W)
+        cnt = 0
+        for hsl in (slice(0, -hs), slice(-hs, -sh), slice(-sh, None)):
+            for wsl in (slice(0, -ws), slice(-ws, -sw), slice(-sw, None)):
+                img[hsl, wsl] = cnt
+                cnt += 1
+        mw = img.view(H // hs, hs, W // ws, ws).permute(0, 2, 1, 3).reshape(-1, hs * ws)
+        d = mw.unsqueeze(1) - mw.unsqueeze(2)
+        out.append(torch.where(d != 0, torch.full_like(d, -100.0), torch.zeros_like(d)))
+    return out
+
+
+def dat_state_dict(in_chans=3, embed_dim=64, split_size=(2, 4), depth=(2,), num_heads=(4,), expansion_factor=2.0, qkv_bias=True, upscale=2,
+                   resi='1conv', upsampler='pixelshuffle', img_size=16, seed=0):  # fmt: skip
+    """Keys (parameters AND buffers) of the reference DAT module (archs/dat/arch.py:828-990).
+
+    BatchNorm running statistics are synthetic too (mean ~ u, var in (0.5, 1.5)): the engine implements the eval-mode network.
+    """
+    sd: OrderedDict = OrderedDict()
+    C = embed_dim
+    hidden = int(C * expansion_factor)
+    split_size = list(split_size)
+    shift_size = [split_size[0] // 2, split_size[1] // 2]
+
+    def lin(name, cout, cin, bias=True):
+        sd[f'{name}.weight'] = synth_tensor(f'{name}.weight', (cout, cin), cin, seed)
+        if bias:
+            sd[f'{name}.bias'] = synth_tensor(f'{name}.bias', (cout,), cin, seed)
+
+    def ln(name, c):
+        sd[f'{name}.weight'] = 1.0 + synth_tensor(f'{name}.weight', (c,), 16, seed)
+        sd[f'{name}.bias'] = synth_tensor(f'{name}.bias', (c,), 16, seed)
+
+    def bn(name, c):
+        ln(name, c)
+        sd[f'{name}.running_mean'] = synth_tensor(f'{name}.running_mean', (c,), 16, seed)
+        sd[f'{name}.running_var'] = 1.0 + 2.0 * synth_tensor(f'{name}.running_var', (c,), 16, seed)
+        sd[f'{name}.num_batches_tracked'] = torch.tensor(100, dtype=torch.int64)
+
+    def dw(name, c):
+        sd[f'{name}.weight'] = synth_tensor(f'{name}.weight', (c, 1, 3, 3), 9, seed)
+        sd[f'{name}.bias'] = synth_tensor(f'{name}.bias', (c,), 9, seed)
+
+    def resi_conv(name):
+        if resi == '1conv':
+            _conv(sd, name, C, C, 3, seed)
+        else:
+            _conv(sd, f'{name}.0', C // 4, C, 3, seed)
+            _conv(sd, f'{name}.2', C // 4, C // 4, 1, seed)
+            _conv(sd, f'{name}.4', C, C // 4, 3, seed)
+
+    def aim(name):
+        dw(f'{name}.dwconv.0', C)
+        bn(f'{name}.dwconv.1', C)
+        _conv(sd, f'{name}.channel_interaction.1', C // 8, C, 1, seed)
+        bn(f'{name}.channel_interaction.2', C // 8)
+        _conv(sd, f'{name}.channel_interaction.4', C, C // 8, 1, seed)
+        _conv(sd, f'{name}.spatial_interaction.0', C // 16, C, 1, seed)
+        bn(f'{name}.spatial_interaction.1', C // 16)
+        _conv(sd, f'{name}.spatial_interaction.3', 1, C // 16, 1, seed)
+
+    def spatial_branch(name, idx, heads):
+        hs, ws = dat_geometry(split_size, idx)
+        bh, bw = torch.arange(1 - hs, hs), torch.arange(1 - ws, ws)
+        sd[f'{name}.rpe_biases'] = torch.stack(torch.meshgrid([bh, bw], indexing='ij')).flatten(1).transpose(0, 1).contiguous().float()
+        coords = torch.stack(torch.meshgrid([torch.arange(hs), torch.arange(ws)], indexing='ij')).flatten(1)
+        rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+        rel[:, :, 0] += hs - 1
+        rel[:, :, 1] += ws - 1
+        rel[:, :, 0] *= 2 * ws - 1
+        sd[f'{name}.relative_position_index'] = rel.sum(-1)
+        pos_dim = ((C // 2) // 4) // 4  # DynamicPosBias(dim // 4): pos_dim = dim // 4 again (arch.py:116, 194)
+        lin(f'{name}.pos.pos_proj', pos_dim, 2)
+        for k, cout in (('pos1', pos_dim), ('pos2', pos_dim), ('pos3', heads)):
+            sd[f'{name}.pos.{k}.0.weight'] = 1.0 + synth_tensor(f'{name}.pos.{k}.0.weight', (pos_dim,), 16, seed)
+            sd[f'{name}.pos.{k}.0.bias'] = synth_tensor(f'{name}.pos.{k}.0.bias', (pos_dim,), 16, seed)
+            lin(f'{name}.pos.{k}.2', cout, pos_dim)
+
+    _conv(sd, 'conv_first', C, in_chans, 3, seed)
+    ln('before_RG.1', C)
+    for i, d in enumerate(depth):
+        heads = num_heads[i]
+        for j in range(d):
+            b = f'layers.{i}.blocks.{j}'
+            ln(f'{b}.norm1', C)
+            if j % 2 == 0:  # DSTB: adaptive spatial attention
+                lin(f'{b}.attn.qkv', 3 * C, C, qkv_bias)
+                lin(f'{b}.attn.proj', C, C)
+                for idx in (0, 1):
+                    spatial_branch(f'{b}.attn.attns.{idx}', idx, heads // 2)
+                if dat_shifted(i, j):
+                    m0, m1 = dat_shift_masks(img_size, img_size, split_size, shift_size)
+                    sd[f'{b}.attn.attn_mask_0'] = m0
+                    sd[f'{b}.attn.attn_mask_1'] = m1
+            else:  # DCTB: adaptive channel attention
+                sd[f'{b}.attn.temperature'] = 1.0 + synth_tensor(f'{b}.attn.temperature', (heads, 1, 1), 4, seed)
+                lin(f'{b}.attn.qkv', 3 * C, C, qkv_bias)
+                lin(f'{b}.attn.proj', C, C)
+            aim(f'{b}.attn')
+            lin(f'{b}.ffn.fc1', hidden, C)
+            ln(f'{b}.ffn.sg.norm', hidden // 2)
+            dw(f'{b}.ffn.sg.conv', hidden // 2)
+            lin(f'{b}.ffn.fc2', C, hidden // 2)
+            ln(f'{b}.norm2', C)
+        resi_conv(f'layers.{i}.conv')
+    ln('norm', C)
+    resi_conv('conv_after_body')
+    if upsampler == 'pixelshuffle':
+        _conv(sd, 'conv_before_upsample.0', 64, C, 3, seed)
+        if upscale == 3:
+            _conv(sd, 'upsample.0', 9 * 64, 64, 3, seed)
+        else:
+            for u in range({1: 0, 2: 1, 4: 2, 8: 3}[upscale]):
+                _conv(sd, f'upsample.{2 * u}', 4 * 64, 64, 3, seed)
+        _conv(sd, 'conv_last', in_chans, 64, 3, seed)
+    else:
+        _conv(sd, 'upsample.0', upscale * upscale * in_chans, C, 3, seed)
+    return sd

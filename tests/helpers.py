@@ -25,10 +25,11 @@ def synth_state_dict(meta):
     from resselt_amd.utils import synth
 
     kw = dict(meta['synth'])
-    if 'blocks' in kw:
-        kw['blocks'] = tuple(kw['blocks'])
+    for k in ('blocks', 'depth', 'num_heads', 'split_size'):
+        if k in kw:
+            kw[k] = tuple(kw[k])
     fn = {'esrgan': synth.rrdbnet_state_dict, 'spanplus': synth.spanplus_state_dict, 'span': synth.span_state_dict,
-          'swinir': getattr(synth, 'swinir_state_dict', None), 'compact': synth.compact_state_dict}[meta['arch']]  # fmt: skip
+          'swinir': getattr(synth, 'swinir_state_dict', None), 'compact': synth.compact_state_dict, 'dat': getattr(synth, 'dat_state_dict', None)}[meta['arch']]  # fmt: skip
     return fn(seed=meta['seed'], **kw)
 
 
@@ -53,4 +54,8 @@ def oracle_forward(meta, sd, x):
         from oracle.compact import compact_forward
 
         return compact_forward(sd, x)
+    if meta['arch'] == 'dat':
+        from oracle.dat import dat_forward
+
+        return dat_forward(sd, x)
     raise KeyError(meta['arch'])

@@ -177,6 +177,25 @@ def compact_cases():
         save(name, dict(arch='compact', synth=kw, seed=seed, metadata=meta_of(model)), x=x, y=model(x))
 
 
+def dat_cases():
+    """DAT end to end, eval mode (BatchNorm running statistics; the loader returns a train-mode module whose DropPath is random)."""
+    cases = [
+        ('dat_x2_e64_s2x4_d3_1_3conv_direct_16x16', dict(embed_dim=64, depth=(3, 1), num_heads=(4, 4), resi='3conv', upsampler='pixelshuffledirect'), (1, 3, 16, 16), 81),
+        ('dat_x2_e64_s2x4_d3_1_3conv_direct_13x18', dict(embed_dim=64, depth=(3, 1), num_heads=(4, 4), resi='3conv', upsampler='pixelshuffledirect'), (1, 3, 13, 18), 82),
+        ('dat_x4_e64_s4x8_d3_ps_b2_20x28', dict(embed_dim=64, depth=(3,), num_heads=(4,), split_size=(4, 8), upscale=4), (2, 3, 20, 28), 83),
+        ('dat_x3_e180_s8x16_d2_ps_24x40', dict(embed_dim=180, depth=(2,), num_heads=(6,), split_size=(8, 16), upscale=3), (1, 3, 24, 40), 84),
+        ('dat_x2_e180_s8x32_d3_ps_40x72', dict(embed_dim=180, depth=(3,), num_heads=(6,), split_size=(8, 32), upscale=2, expansion_factor=4.0, img_size=64), (1, 3, 40, 72), 85),
+        ('dat_light_x2_e60_s8x32_d4_direct_33x47', dict(embed_dim=60, depth=(4,), num_heads=(6,), split_size=(8, 32), upscale=2, resi='3conv', upsampler='pixelshuffledirect', img_size=64), (1, 3, 33, 47), 86),
+    ]
+    for name, kw, shape, seed in cases:
+        sd = synth.dat_state_dict(seed=seed, **kw)
+        model = resselt.load_from_state_dict(dict(sd)).eval()
+        x = synth.synth_input(shape, seed)
+        y = model(x)
+        kw = {k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()}
+        save(name, dict(arch='dat', synth=kw, seed=seed, metadata=meta_of(model), mode='eval'), x=x, y=y)
+
+
 def registry_cases():
     """Detection order facts: which reference architecture claims each synthetic checkpoint."""
     claims = {}
@@ -187,6 +206,7 @@ def registry_cases():
         ('span', synth.span_state_dict()),
         ('compact', synth.compact_state_dict(num_conv=2)),
         ('swinir', synth.swinir_state_dict()),
+        ('dat', synth.dat_state_dict()),
     ):
         for arch in resselt.archs.internal_registry.store.values():
             if arch.detect(sd):
@@ -196,7 +216,7 @@ def registry_cases():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['esrgan', 'blocks', 'span', 'compact', 'registry', 'swinir']
+    which = sys.argv[1:] or ['esrgan', 'blocks', 'span', 'compact', 'registry', 'swinir', 'dat']
     if 'esrgan' in which:
         esrgan_cases()
     if 'blocks' in which:
@@ -205,6 +225,8 @@ if __name__ == '__main__':
         span_cases()
     if 'compact' in which:
         compact_cases()
+    if 'dat' in which:
+        dat_cases()
     if 'registry' in which:
         registry_cases()
     if 'swinir' in which:
