@@ -225,6 +225,142 @@ typedef struct rsa_window_attn_params {
 
 int rsa_window_attention(const rsa_window_attn_params* p, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------- DAT ops
+ * Building blocks of the Dual Aggregation Transformer path (reference archs/dat/arch.py).  Tokens are pixels; every map is in
+ * the split-plane layout [N][planes][H][W][8] (bf16 hi, optional lo).  Attention maps use the head-padded channel layout of
+ * rsa_window_attention: head h owns channels [32h, 32h+32), head_dim <= 32, pad channels are zero. */
+
+/* Rectangular (shifted) window attention core of Spatial_Attention.forward (arch.py:224-267) together with the zero padding,
+ * torch.roll, img2windows / windows2img and calculate_mask of Adaptive_Spatial_Attention.forward (arch.py:336-411, 446-492).
+ * One call = one branch (one window orientation) over `heads` consecutive head slots starting at `head0`. */
+typedef struct rsa_rect_attn_params {
+  int32_t batch;
+  int32_t H, W;             /* token map size; tokens outside it (padding up to Hp x Wp) have q = k = v = 0 */
+  int32_t Hp, Wp;           /* padded grid: multiples of win_h / win_w, >= H / W */
+  int32_t win_h, win_w;     /* win_h * win_w <= 256 */
+  int32_t shift_h, shift_w; /* 0 (no mask) or the cyclic shift; 0 <= shift < win */
+  int32_t heads;            /* head slots this call processes */
+  int32_t head0;            /* first of them */
+  int32_t heads_total;      /* head slots per q / k / v group: q planes [0, 4*heads_total), then k, then v */
+  int32_t products;         /* 1 or 3 */
+  const void* qkv_hi;
+  const void* qkv_lo;       /* may be NULL when products == 1 */
+  int64_t qkv_plane_stride; /* 16-byte units */
+  int64_t qkv_batch_stride;
+  const float* bias_frag;   /* [heads][T][T][64][16] f32, T = tiles of 32 tokens (1, 2, 4 or 8): S^T accumulator order, -1e30 on padded keys */
+  void* out_hi;             /* planes [(head0 + h)*4, +4) */
+  void* out_lo;
+  int64_t out_plane_stride;
+  int64_t out_batch_stride;
+} rsa_rect_attn_params;
+int rsa_rect_attention(const rsa_rect_attn_params* p, void* stream);
+
+/* Channel ("transposed") attention weights of Adaptive_Channel_Attention.forward (arch.py:577-585):
+ *   attn[b][h] = softmax_j( normalize(q)[i] . normalize(k)[j] * temperature[h] )   over ALL tokens of image b,
+ * written as the packed bf16 hi/lo weights of a block-diagonal 1x1 convolution (rsa_conv2d, cin = cout = 32*heads) so that
+ * `attn @ v` is one more launch of the convolution kernel.  Two deterministic stages (per-chunk partial Gram matrices in
+ * `workspace`, then one workgroup per (image, head)); no atomics. */
+typedef struct rsa_channel_attn_params {
+  int32_t batch;
+  int32_t H, W;
+  int32_t heads;
+  int32_t head_dim;          /* <= 32 */
+  int32_t products;          /* layout of w_packed: 3 = hi+lo, 1 = hi only */
+  const void* q_hi;          /* planes [4h, 4h+4) = head h */
+  const void* q_lo;          /* may be NULL */
+  const void* k_hi;
+  const void* k_lo;
+  int64_t plane_stride;      /* 16-byte units (same for q and k) */
+  int64_t batch_stride;
+  const float* temperature;  /* [heads] */
+  float* workspace;          /* >= rsa_channel_attn_workspace_bytes() */
+  void* w_packed;            /* [batch] blobs of rsa_packed_weight_bytes(32*heads, 4*heads, 1, products); off-diagonal blocks must be zero */
+} rsa_channel_attn_params;
+int64_t rsa_channel_attn_workspace_bytes(int32_t batch, int32_t H, int32_t W, int32_t heads);
+int rsa_channel_attention_weights(const rsa_channel_attn_params* p, void* stream);
+
+/* Depthwise 3x3 convolution, zero padding 1 (arch.py:52, 322, 540):  out = act(dw(x') + bias) [* mul]
+ * with x' = x, or x' = (x - mean_p) * rstd_p * gamma_c + beta_c when `stats` is given (the LayerNorm of SpatialGate, arch.py:55-59,
+ * applied on the fly from per-pixel statistics; padding stays zero AFTER the normalisation).  BatchNorm(eval) is folded by the host. */
+typedef struct rsa_dwconv_params {
+  int32_t batch;
+  int32_t H, W;
+  int32_t planes;            /* 8 channels each */
+  int32_t act;               /* RSA_ACT_NONE or RSA_ACT_GELU */
+  const void* in_hi;
+  const void* in_lo;         /* may be NULL */
+  int64_t in_plane_stride;
+  int64_t in_batch_stride;
+  const float* weight;       /* [planes*8][9] */
+  const float* bias;         /* [planes*8] */
+  const float* stats;        /* optional [batch][H*W][2] = (mean, rstd) */
+  const float* gamma;        /* [planes*8], with stats */
+  const float* beta;
+  const void* mul_hi;        /* optional elementwise multiplier map */
+  const void* mul_lo;
+  int64_t mul_plane_stride;
+  int64_t mul_batch_stride;
+  void* out_hi;
+  void* out_lo;              /* may be NULL */
+  int64_t out_plane_stride;
+  int64_t out_batch_stride;
+} rsa_dwconv_params;
+int rsa_dwconv3x3(const rsa_dwconv_params* p, void* stream);
+
+/* Per-pixel LayerNorm statistics over channels [0, C) of a plane range: stats[b][pixel] = (mean, 1/sqrt(var + eps)). */
+int rsa_plane_stats(const void* in_hi, const void* in_lo, int64_t plane_stride, int64_t batch_stride, int32_t batch, int32_t H, int32_t W,
+                    int32_t C, float eps, float* stats, void* stream);
+
+/* channel_interaction of the AIM (arch.py:326-332): gate[b][c] = sigmoid( W2 . gelu(W1 . mean_pixels(x[b]) + b1) + b2 ).
+ * BatchNorm(eval) folded into W1/b1 by the host.  Deterministic two-stage mean; `workspace` >= rsa_channel_gate_workspace_bytes(). */
+typedef struct rsa_channel_gate_params {
+  int32_t batch;
+  int32_t H, W;
+  int32_t planes;            /* C = 8*planes (pad channels carry zero weights) */
+  int32_t hidden;            /* <= 64 */
+  const void* in_hi;
+  const void* in_lo;         /* may be NULL */
+  int64_t in_plane_stride;
+  int64_t in_batch_stride;
+  const float* w1;           /* [hidden][C] */
+  const float* b1;           /* [hidden] */
+  const float* w2;           /* [C][hidden] */
+  const float* b2;           /* [C] */
+  float* workspace;
+  float* gate;               /* [batch][C] */
+} rsa_channel_gate_params;
+int64_t rsa_channel_gate_workspace_bytes(int32_t batch, int32_t H, int32_t W, int32_t planes);
+int rsa_channel_gate(const rsa_channel_gate_params* p, void* stream);
+
+/* Adaptive Interaction Module combine (arch.py:494-508 and 595-607):  s = w2 . gelu(W1 . src[p] + b1) + b2  (spatial_interaction, BN folded)
+ *   mode 0 (spatial block): src = att,  out = att * gate[c] + sigmoid(s) * conv
+ *   mode 1 (channel block): src = conv, out = att * sigmoid(s) + conv * gate[c] */
+typedef struct rsa_aim_params {
+  int32_t batch;
+  int32_t H, W;
+  int32_t planes;
+  int32_t hidden;            /* <= 16 */
+  int32_t mode;
+  const void* att_hi;
+  const void* att_lo;
+  int64_t att_plane_stride;
+  int64_t att_batch_stride;
+  const void* conv_hi;
+  const void* conv_lo;
+  int64_t conv_plane_stride;
+  int64_t conv_batch_stride;
+  const float* gate;         /* [batch][8*planes] */
+  const float* w1;           /* [hidden][8*planes] */
+  const float* b1;           /* [hidden] */
+  const float* w2;           /* [hidden] */
+  float b2;
+  void* out_hi;
+  void* out_lo;
+  int64_t out_plane_stride;
+  int64_t out_batch_stride;
+} rsa_aim_params;
+int rsa_aim_combine(const rsa_aim_params* p, void* stream);
+
 /* version / errors */
 int rsa_version(void);
 const char* rsa_last_error_string(void);

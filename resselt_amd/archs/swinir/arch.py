@@ -71,8 +71,8 @@ def bias_fragments(table: torch.Tensor, index: torch.Tensor, window: int) -> tor
     return out.contiguous()
 
 
-def regroup_qkv(w: torch.Tensor, b: torch.Tensor | None, heads: int) -> tuple[torch.Tensor, torch.Tensor]:
-    """[3C, C] -> [3*heads*32, C]: row (which, head, d) <- which*C + head*hd + d, zero rows for d >= hd; q rows scaled."""
+def regroup_qkv(w: torch.Tensor, b: torch.Tensor | None, heads: int, scale_q: bool = True) -> tuple[torch.Tensor, torch.Tensor]:
+    """[3C, C] -> [3*heads*32, C]: row (which, head, d) <- which*C + head*hd + d, zero rows for d >= hd; q rows scaled by hd^-0.5."""
     c3, c = w.shape
     hd = c // heads
     wn = torch.zeros((3, heads, HEAD_PAD, c), dtype=torch.float32, device=w.device)
@@ -80,9 +80,10 @@ def regroup_qkv(w: torch.Tensor, b: torch.Tensor | None, heads: int) -> tuple[to
     wn[:, :, :hd] = w.to(torch.float32).reshape(3, heads, hd, c)
     if b is not None:
         bn[:, :, :hd] = b.to(torch.float32).reshape(3, heads, hd)
-    scale = hd**-0.5
-    wn[0] *= scale
-    bn[0] *= scale
+    if scale_q:
+        scale = hd**-0.5
+        wn[0] *= scale
+        bn[0] *= scale
     return wn.reshape(3 * heads * HEAD_PAD, c), bn.reshape(-1)
 
 

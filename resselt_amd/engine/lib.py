@@ -124,6 +124,138 @@ class WindowAttnParams(C.Structure):
     ]
 
 
+class RectAttnParams(C.Structure):
+    """Mirror of ``struct rsa_rect_attn_params``."""
+
+    _fields_ = [
+        ('batch', C.c_int32),
+        ('H', C.c_int32),
+        ('W', C.c_int32),
+        ('Hp', C.c_int32),
+        ('Wp', C.c_int32),
+        ('win_h', C.c_int32),
+        ('win_w', C.c_int32),
+        ('shift_h', C.c_int32),
+        ('shift_w', C.c_int32),
+        ('heads', C.c_int32),
+        ('head0', C.c_int32),
+        ('heads_total', C.c_int32),
+        ('products', C.c_int32),
+        ('qkv_hi', C.c_void_p),
+        ('qkv_lo', C.c_void_p),
+        ('qkv_plane_stride', C.c_int64),
+        ('qkv_batch_stride', C.c_int64),
+        ('bias_frag', C.c_void_p),
+        ('out_hi', C.c_void_p),
+        ('out_lo', C.c_void_p),
+        ('out_plane_stride', C.c_int64),
+        ('out_batch_stride', C.c_int64),
+    ]
+
+
+class ChannelAttnParams(C.Structure):
+    """Mirror of ``struct rsa_channel_attn_params``."""
+
+    _fields_ = [
+        ('batch', C.c_int32),
+        ('H', C.c_int32),
+        ('W', C.c_int32),
+        ('heads', C.c_int32),
+        ('head_dim', C.c_int32),
+        ('products', C.c_int32),
+        ('q_hi', C.c_void_p),
+        ('q_lo', C.c_void_p),
+        ('k_hi', C.c_void_p),
+        ('k_lo', C.c_void_p),
+        ('plane_stride', C.c_int64),
+        ('batch_stride', C.c_int64),
+        ('temperature', C.c_void_p),
+        ('workspace', C.c_void_p),
+        ('w_packed', C.c_void_p),
+    ]
+
+
+class DwConvParams(C.Structure):
+    """Mirror of ``struct rsa_dwconv_params``."""
+
+    _fields_ = [
+        ('batch', C.c_int32),
+        ('H', C.c_int32),
+        ('W', C.c_int32),
+        ('planes', C.c_int32),
+        ('act', C.c_int32),
+        ('in_hi', C.c_void_p),
+        ('in_lo', C.c_void_p),
+        ('in_plane_stride', C.c_int64),
+        ('in_batch_stride', C.c_int64),
+        ('weight', C.c_void_p),
+        ('bias', C.c_void_p),
+        ('stats', C.c_void_p),
+        ('gamma', C.c_void_p),
+        ('beta', C.c_void_p),
+        ('mul_hi', C.c_void_p),
+        ('mul_lo', C.c_void_p),
+        ('mul_plane_stride', C.c_int64),
+        ('mul_batch_stride', C.c_int64),
+        ('out_hi', C.c_void_p),
+        ('out_lo', C.c_void_p),
+        ('out_plane_stride', C.c_int64),
+        ('out_batch_stride', C.c_int64),
+    ]
+
+
+class ChannelGateParams(C.Structure):
+    """Mirror of ``struct rsa_channel_gate_params``."""
+
+    _fields_ = [
+        ('batch', C.c_int32),
+        ('H', C.c_int32),
+        ('W', C.c_int32),
+        ('planes', C.c_int32),
+        ('hidden', C.c_int32),
+        ('in_hi', C.c_void_p),
+        ('in_lo', C.c_void_p),
+        ('in_plane_stride', C.c_int64),
+        ('in_batch_stride', C.c_int64),
+        ('w1', C.c_void_p),
+        ('b1', C.c_void_p),
+        ('w2', C.c_void_p),
+        ('b2', C.c_void_p),
+        ('workspace', C.c_void_p),
+        ('gate', C.c_void_p),
+    ]
+
+
+class AimParams(C.Structure):
+    """Mirror of ``struct rsa_aim_params``."""
+
+    _fields_ = [
+        ('batch', C.c_int32),
+        ('H', C.c_int32),
+        ('W', C.c_int32),
+        ('planes', C.c_int32),
+        ('hidden', C.c_int32),
+        ('mode', C.c_int32),
+        ('att_hi', C.c_void_p),
+        ('att_lo', C.c_void_p),
+        ('att_plane_stride', C.c_int64),
+        ('att_batch_stride', C.c_int64),
+        ('conv_hi', C.c_void_p),
+        ('conv_lo', C.c_void_p),
+        ('conv_plane_stride', C.c_int64),
+        ('conv_batch_stride', C.c_int64),
+        ('gate', C.c_void_p),
+        ('w1', C.c_void_p),
+        ('b1', C.c_void_p),
+        ('w2', C.c_void_p),
+        ('b2', C.c_float),
+        ('out_hi', C.c_void_p),
+        ('out_lo', C.c_void_p),
+        ('out_plane_stride', C.c_int64),
+        ('out_batch_stride', C.c_int64),
+    ]
+
+
 # every symbol include/resselt_amd.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = (
     'rsa_version',
@@ -137,6 +269,14 @@ EXPORTS = (
     'rsa_dysample',
     'rsa_layernorm',
     'rsa_window_attention',
+    'rsa_rect_attention',
+    'rsa_channel_attn_workspace_bytes',
+    'rsa_channel_attention_weights',
+    'rsa_dwconv3x3',
+    'rsa_plane_stats',
+    'rsa_channel_gate_workspace_bytes',
+    'rsa_channel_gate',
+    'rsa_aim_combine',
 )
 
 
@@ -184,6 +324,17 @@ def load() -> C.CDLL:
     lib.rsa_layernorm.restype = C.c_int
     lib.rsa_window_attention.argtypes = [C.POINTER(WindowAttnParams), C.c_void_p]
     lib.rsa_window_attention.restype = C.c_int
+    for name, struct in (('rsa_rect_attention', RectAttnParams), ('rsa_channel_attention_weights', ChannelAttnParams), ('rsa_dwconv3x3', DwConvParams),
+                         ('rsa_channel_gate', ChannelGateParams), ('rsa_aim_combine', AimParams)):  # fmt: skip
+        getattr(lib, name).argtypes = [C.POINTER(struct), C.c_void_p]
+        getattr(lib, name).restype = C.c_int
+    lib.rsa_channel_attn_workspace_bytes.argtypes = [C.c_int32] * 4
+    lib.rsa_channel_attn_workspace_bytes.restype = C.c_int64
+    lib.rsa_channel_gate_workspace_bytes.argtypes = [C.c_int32] * 4
+    lib.rsa_channel_gate_workspace_bytes.restype = C.c_int64
+    lib.rsa_plane_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
+                                    C.c_void_p]  # fmt: skip
+    lib.rsa_plane_stats.restype = C.c_int
     _lib = lib
     return lib
 

@@ -128,7 +128,7 @@ def test_esrgan_roundtrip_and_new_arch_fix():
 
 def test_detection_claims_match_reference():
     meta, _ = load_golden('registry_claims')
-    ours = {'rrdbnet_old': 'ESRGAN', 'spanplus_ps': 'spanplus', 'spanplus_dys': 'spanplus', 'span': 'SPAN', 'compact': 'Compact', 'swinir': 'SwinIR'}
+    ours = {'rrdbnet_old': 'ESRGAN', 'spanplus_ps': 'spanplus', 'spanplus_dys': 'spanplus', 'span': 'SPAN', 'compact': 'Compact', 'swinir': 'SwinIR', 'dat': 'dat'}
     for tag, uid in ours.items():
         assert meta['claims'][tag] == uid
     built = {
@@ -138,6 +138,7 @@ def test_detection_claims_match_reference():
         'span': synth.span_state_dict(),
         'compact': synth.compact_state_dict(num_conv=2),
         'swinir': synth.swinir_state_dict(),
+        'dat': synth.dat_state_dict(),
     }
     for tag, sd in built.items():
         hit = [a.id for a in resselt_amd.archs.internal_registry if a.detect(sd)]
