@@ -47,6 +47,10 @@ def main():
         'C4_swinir_L_x4_bf16_1024': (
             synth.swinir_state_dict(embed_dim=240, depths=[6] * 9, num_heads=[8] * 9, upscale=4, upsampler='nearest+conv', resi='3conv'),
             (1, 3, 1024, 1024), torch.bfloat16, 3_833_694, 27_600),
+        # SURVEY.md §8 a17 (no BASELINE config): the published DAT x4 (embed 180, 6 groups x 6 blocks, 6 heads, split 8x32, expansion 4)
+        'dat_x4_bf16_512': (
+            synth.dat_state_dict(embed_dim=180, depth=(6,) * 6, num_heads=(6,) * 6, split_size=(8, 32), expansion_factor=4.0, upscale=4, img_size=64),
+            (1, 3, 512, 512), torch.bfloat16, None, None),
     }  # fmt: skip
     for name, (sd, shape, dt, flop_px, bytes_px) in cases.items():
         if args.only and args.only not in name:
