@@ -100,14 +100,19 @@ def main():
             raise SystemExit('launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the engine has no CPU path')
-    dev = torch.device('cuda', local_rank)
+    # RSA_DIST_BACKEND=gloo rehearses the N > 1 code path with several ranks on ONE GPU (RCCL refuses two ranks per device)
+    backend = os.environ.get('RSA_DIST_BACKEND', 'nccl')
+    dev = torch.device('cuda', local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import resselt_amd
     from resselt_amd.utils import synth
