@@ -1,7 +1,7 @@
 """Build ``libresselt_amd.so`` in-tree with hipcc for gfx950 (``python -m resselt_amd.build``).
 
 The shared object lands next to this file so that it travels with the repository snapshot to the GPU
-box (it is git-ignored, not gpurun-ignored).  No JIT, no torch extension machinery: one hipcc invocation.
+box (it is git-ignored, not gpurun-ignored).  No JIT, no torch extension machinery: one hipcc per source file + one link.
 """
 
 from __future__ import annotations
@@ -34,6 +34,15 @@ def _hash() -> str:
     return h.hexdigest()
 
 
+def _compile(args) -> str:
+    hipcc, src, obj, verbose = args
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, src, '-o', obj]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return obj
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     want = _hash()
     if not force and os.path.exists(OUT) and os.path.exists(STAMP) and open(STAMP).read().strip() == want:
@@ -41,8 +50,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
         raise RuntimeError('hipcc not found: cannot build libresselt_amd.so')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC,
-           *sources(), '-o', OUT]  # fmt: skip
+    # one hipcc per translation unit, in parallel (the convolution kernels dominate the compile time), then one link
+    objdir = os.path.join(ROOT, 'build', 'obj')
+    os.makedirs(objdir, exist_ok=True)
+    jobs = [(hipcc, src, os.path.join(objdir, os.path.basename(src)[:-4] + '.o'), verbose) for src in sources()]
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:
+        objs = list(pool.map(_compile, jobs))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', OUT]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)
