@@ -115,20 +115,24 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
     return;
   }
 #endif
+  // li / lg are fixed for the whole kernel, so the compiler hoists every 64-bit per-lane address component derived from them out
+  // of the persistent tile loop, finds no registers for them across the MFMA loop and spills them: ~40 scratch reloads per tile in
+  // the epilogue, each waiting (vmcnt, in order) for the stores before it.  Laundering the two lane ids makes the derived values
+  // tile-local: a handful of VALU instructions per fragment instead.
+  asm volatile("" : "+v"(li), "+v"(lg));
   const int64_t HW = (int64_t)p.H * p.W;
   const int64_t pix0 = (int64_t)y0 * p.W + x0;  // uniform
   const int p4 = (p.cout + 3) >> 2;
   const int cout8 = (p.cout + 7) & ~7;
   const int ctile0 = slab * NCT + wct * CTW;
 
-  uint32_t lpix[8];
-  bool pvalid[8];
-#pragma unroll
-  for (int pt = 0; pt < 8; ++pt) {
-    const int ry = wpx * 4 + (pt >> 1), rx = (pt & 1) * 16 + li;
-    lpix[pt] = (uint32_t)(ry * p.W + rx);
-    pvalid[pt] = (y0 + ry < p.H) && (x0 + rx < p.W);
-  }
+  // per-lane pixel offset / validity of pixel-tile pt, recomputed at every use from ONE lane register and uniform terms: holding
+  // them in arrays (and the 64-bit addresses the compiler derived from them) cost the 2-cout-tile epilogue ~40 scratch reloads per
+  // tile, each of which had to wait (vmcnt, in order) for the stores issued before it
+  const uint32_t lbase = (uint32_t)(wpx * 4 * p.W + li);
+  const bool xv0 = x0 + li < p.W, xv1 = x0 + 16 + li < p.W;
+  auto lpix_of = [&](int pt) -> uint32_t { return lbase + (uint32_t)((pt >> 1) * p.W + (pt & 1) * 16); };
+  auto pvalid_of = [&](int pt) -> bool { return (y0 + wpx * 4 + (pt >> 1) < p.H) && ((pt & 1) ? xv1 : xv0); };
 
   // vmcnt retires IN ORDER and counts stores: a load issued after a store cannot be waited for before that store's write is
   // acknowledged.  So every load of the epilogue is issued ahead of the stores it would otherwise queue behind: bias / slope
@@ -175,11 +179,11 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int pt = pp * 2 + e;
-        ok[e] = pvalid[pt] && cvalid;
+        ok[e] = pvalid_of(pt) && cvalid;
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[e][r] = acc[pt][ct][r] + bias[r];
         if (OUTK == 0) {
-          const uint32_t foff = (f32lane + lpix[pt]) * 16u;
+          const uint32_t foff = (f32lane + lpix_of(pt)) * 16u;
           if (AC == AC_GATE) {
             f32x4 rr = {0.f, 0.f, 0.f, 0.f};
             if (ok[e] && has_f32grp) rr = *(const f32x4*)(r1b + foff);
@@ -230,8 +234,8 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
           const uint4 uh = odd ? make_uint4(rh[0], rh[1], h[1][0], h[1][1]) : make_uint4(h[0][0], h[0][1], rh[0], rh[1]);
           const uint4 ul = odd ? make_uint4(rl[0], rl[1], l[1][0], l[1][1]) : make_uint4(l[0][0], l[0][1], rl[0], rl[1]);
           // the partner lane has the same pixel column li and the same plane; both halves are valid together (same cvalid)
-          if (pvalid[pt] && cvalid) {
-            const uint32_t uoff = (pllane + lpix[pt]) * 16u;
+          if (pvalid_of(pt) && cvalid) {
+            const uint32_t uoff = (pllane + lpix_of(pt)) * 16u;
             *(uint4*)(ohb + uoff) = uh;
             if (p.out_lo != nullptr) *(uint4*)(olb + uoff) = ul;
           }
