@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B several builds of libresselt_amd.so in ONE process (interleaved rounds, median + min per variant) on single conv layers.
 
-usage: conv_ab.py name=path.so [name=path.so ...] -- cin,cout[,H,W] ...
+usage: conv_ab.py name=path.so [name=path.so ...] -- cin,cout[,H,W[,ksize]] ...
 """
 
 import ctypes as C
@@ -24,7 +24,7 @@ libs = dict(a.split('=') for a in args[:split])
 configs = []
 for a in args[split + 1 :]:
     v = [int(x) for x in a.split(',')]
-    configs.append((v[0], v[1], v[2] if len(v) > 2 else 1080, v[3] if len(v) > 3 else 1920))
+    configs.append((v[0], v[1], v[2] if len(v) > 2 else 1080, v[3] if len(v) > 3 else 1920, v[4] if len(v) > 4 else 3))
 dev = torch.device('cuda:0')
 handles = {}
 for name, path in libs.items():
@@ -34,8 +34,8 @@ for name, path in libs.items():
     handles[name] = h
 rounds = int(os.environ.get('AB_ROUNDS', 7))
 for products in (3, 1):
-    for cin, cout, H, W in configs:
-        w = (torch.rand((cout, cin, 3, 3)) - 0.5) * 0.1
+    for cin, cout, H, W, ks in configs:
+        w = (torch.rand((cout, cin, ks, ks)) - 0.5) * 0.1
         wts = ops.ConvWeights.from_oihw(w, torch.zeros(cout), products, device=dev)
         x = tensors.Planes.empty(1, cin // 8, H, W, dev)
         x.hi.copy_(torch.randn(x.hi.shape, device=dev).to(torch.bfloat16))
@@ -55,5 +55,5 @@ for products in (3, 1):
                 torch.cuda.synchronize()
                 if r:
                     times[n].append(e0.elapsed_time(e1) / 3)
-        flop = 2.0 * cin * 9 * cout * H * W * products
-        print(f'products={products} {cin}->{cout} {H}x{W}: ' + '  '.join(f'{n}: med {statistics.median(t):.3f} min {min(t):.3f} ms ({flop / statistics.median(t) / 1e9:.0f} TF issued)' for n, t in times.items()), flush=True)
+        flop = 2.0 * cin * ks * ks * cout * H * W * products
+        print(f'products={products} {cin}->{cout} k{ks} {H}x{W}: ' + '  '.join(f'{n}: med {statistics.median(t):.3f} min {min(t):.3f} ms ({flop / statistics.median(t) / 1e9:.0f} TF issued)' for n, t in times.items()), flush=True)
