@@ -11,9 +11,10 @@ from .dat import DatArch
 from .esrgan import ESRGANArch
 from .span import SPANArch
 from .spanplus import SpanPlusArch
+from .spanpp import SpanPPArch
 from .swinir import SwinIRArch
 
 internal_registry = Registry()
-# relative order follows the reference's registry walk (tests/golden/registry_claims.npz): ESRGAN, dat, Compact, spanplus, SwinIR, ..., SPAN
-for _arch in (ESRGANArch, DatArch, CompactArch, SpanPlusArch, SwinIRArch, SPANArch):
+# relative order follows the reference's registry walk (tests/golden/registry_claims.npz): ESRGAN, dat, Compact, spanplus, SwinIR, SpanPP, ..., SPAN
+for _arch in (ESRGANArch, DatArch, CompactArch, SpanPlusArch, SwinIRArch, SpanPPArch, SPANArch):
     internal_registry.add(_arch())

@@ -366,3 +366,37 @@ def dat_state_dict(in_chans=3, embed_dim=64, split_size=(2, 4), depth=(2,), num_
     else:
         _conv(sd, 'upsample.0', upscale * upscale * in_chans, C, 3, seed)
     return sd
+
+
+def _repconv(sd, name, cout, cin, seed):
+    """Keys of SpanPP's RepConv (archs/spanpp/arch.py:152-192): SeqConv3x3 (k0, b0, k1, b1), a plain 3x3, a Conv3XC, the fused conv, alpha."""
+    mid = 2 * cout
+    sd[f'{name}.alpha'] = 1.0 + synth_tensor(f'{name}.alpha', (3,), 4, seed)
+    sd[f'{name}.conv1.k0'] = synth_tensor(f'{name}.conv1.k0', (mid, cin, 1, 1), cin, seed)
+    sd[f'{name}.conv1.b0'] = synth_tensor(f'{name}.conv1.b0', (mid,), cin, seed)
+    sd[f'{name}.conv1.k1'] = synth_tensor(f'{name}.conv1.k1', (cout, mid, 3, 3), mid * 9, seed)
+    sd[f'{name}.conv1.b1'] = synth_tensor(f'{name}.conv1.b1', (cout,), mid * 9, seed)
+    _conv(sd, f'{name}.conv2', cout, cin, 3, seed)
+    _conv3xc(sd, f'{name}.conv3', cout, cin, 2, seed)
+    _conv(sd, f'{name}.conv_3x3_rep', cout, cin, 3, seed)
+
+
+def spanpp_state_dict(num_in_ch=3, feature_channels=48, scale_list=(1, 2, 3, 4), implicit_dim=256, latent_layers=4, seed=0):
+    """Keys of the reference SpanPP module (archs/spanpp/arch.py:315-373), ``MetaIGConv`` buffer included."""
+    sd: OrderedDict = OrderedDict()
+    fc = feature_channels
+    _repconv(sd, 'conv0', fc, num_in_ch, seed)
+    for i in range(1, 7):
+        for r in ('c1_r', 'c2_r', 'c3_r'):
+            _repconv(sd, f'block_{i}.{r}', fc, fc, seed)
+    _conv(sd, 'conv_cat', fc, 4 * fc, 1, seed)
+    _repconv(sd, 'conv_2', fc, fc, seed)
+    # freq / amplitude are randn * 0.02 in the reference; a larger spread makes the generated kernels non-trivial
+    sd['upsampler.freq'] = synth_tensor('upsampler.freq', (fc * 9, implicit_dim, 1, 1), 1, seed, 0.5)
+    sd['upsampler.amplitude'] = synth_tensor('upsampler.amplitude', (fc * 9, implicit_dim, 1, 1), 1, seed, 0.5)
+    _conv(sd, 'upsampler.phase', implicit_dim // 2, 1, 1, seed)
+    for l in range(latent_layers):
+        _conv(sd, f'upsampler.query_kernel.{2 * l}', implicit_dim, implicit_dim, 1, seed)
+    _conv(sd, f'upsampler.query_kernel.{2 * latent_layers}', 3, implicit_dim, 1, seed)
+    sd['MetaIGConv'] = torch.tensor(sorted(set(scale_list)), dtype=torch.uint8)
+    return sd

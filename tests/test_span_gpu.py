@@ -30,6 +30,25 @@ def test_span_family_matches_reference_vectors(device, name):
     assert err <= _tol(arr['y']), f'{name}: max-abs {err:.3e} (|y|max {arr["y"].abs().max():.3f})'
 
 
+@pytest.mark.parametrize('name', golden_names('spanpp_'))
+def test_spanpp_matches_reference_vectors(device, name):
+    """SpanPP (RepConv folds + implicit-grid upsampler kernels generated at pack time) against the reference in eval mode, every head scale."""
+    meta, arr = load_golden(name)
+    sd = synth_state_dict(meta)
+    m = resselt_amd.load_from_state_dict(dict(sd)).to(device)
+    assert vars(m.parameters_info) == {k: meta['metadata'][k] for k in ('in_channels', 'out_channels', 'upscale', 'name')}
+    x = arr['x'].to(device)
+    y = m(x) if meta['scale'] is None else m(x, meta['scale'])
+    torch.cuda.synchronize()
+    assert y.shape == arr['y'].shape
+    err = (y.cpu() - arr['y']).abs().max().item()
+    assert err <= _tol(arr['y']), f'{name}: max-abs {err:.3e} (|y|max {arr["y"].abs().max():.3f})'
+    with pytest.raises(KeyError):
+        m(x, 7)  # a scale outside scale_list, as in the reference
+    y2 = m(x, 2)  # switching heads rebuilds the plan
+    assert y2.shape[-1] == 2 * x.shape[-1]
+
+
 @pytest.mark.parametrize('ups', ['ps', 'dys'])
 def test_spanplus_x4_fp16_batch_vs_oracle(device, ups):
     """Shape of BASELINE config 3 (SPANPlus 4x, fp16 tensors, batched tiles), reduced to a size the oracle finishes quickly."""

@@ -196,6 +196,24 @@ def dat_cases():
         save(name, dict(arch='dat', synth=kw, seed=seed, metadata=meta_of(model), mode='eval'), x=x, y=y)
 
 
+def spanpp_cases():
+    """SpanPP end to end in eval mode (the only mode the reference module can run in: IGConv reads a table that .eval() fills)."""
+    cases = [
+        ('spanpp_fc48_x2_default_24x40', dict(), (1, 3, 24, 40), None, 91),
+        ('spanpp_fc48_x4_b2_17x23', dict(), (2, 3, 17, 23), 4, 92),
+        ('spanpp_fc32_x3_id64_l2_19x21', dict(feature_channels=32, implicit_dim=64, latent_layers=2), (1, 3, 19, 21), 3, 93),
+        ('spanpp_fc32_x1_scales124_16x16', dict(feature_channels=32, implicit_dim=64, latent_layers=2, scale_list=(1, 2, 4)), (1, 3, 16, 16), 1, 94),
+    ]
+    for name, kw, shape, scale, seed in cases:
+        sd = synth.spanpp_state_dict(seed=seed, **kw)
+        model = resselt.load_from_state_dict(dict(sd)).eval()
+        x = synth.synth_input(shape, seed)
+        y = model(x) if scale is None else model(x, scale)
+        kw = {k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()}
+        meta = meta_of(model)
+        save(name, dict(arch='spanpp', synth=kw, seed=seed, scale=scale, metadata=meta, mode='eval'), x=x, y=y)
+
+
 def registry_cases():
     """Detection order facts: which reference architecture claims each synthetic checkpoint."""
     claims = {}
@@ -207,6 +225,7 @@ def registry_cases():
         ('compact', synth.compact_state_dict(num_conv=2)),
         ('swinir', synth.swinir_state_dict()),
         ('dat', synth.dat_state_dict()),
+        ('spanpp', synth.spanpp_state_dict(feature_channels=16, implicit_dim=32, latent_layers=1)),
     ):
         for arch in resselt.archs.internal_registry.store.values():
             if arch.detect(sd):
@@ -216,7 +235,7 @@ def registry_cases():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['esrgan', 'blocks', 'span', 'compact', 'registry', 'swinir', 'dat']
+    which = sys.argv[1:] or ['esrgan', 'blocks', 'span', 'compact', 'registry', 'swinir', 'dat', 'spanpp']
     if 'esrgan' in which:
         esrgan_cases()
     if 'blocks' in which:
@@ -227,6 +246,8 @@ if __name__ == '__main__':
         compact_cases()
     if 'dat' in which:
         dat_cases()
+    if 'spanpp' in which:
+        spanpp_cases()
     if 'registry' in which:
         registry_cases()
     if 'swinir' in which:
