@@ -94,13 +94,33 @@ __global__ __launch_bounds__(GK_WAVES * 64, 2) void gemm_k1_kernel(const rsa_con
         }
     }
 
+    // bias / PReLU slopes of this wave's cout tiles: loaded once per pass, not per tile -- a load inside the tile epilogue would have
+    // to wait (vmcnt retires in order) for the tile DMA issued just before it
+    f32x4 biasv[CTW], slopev[CTW];
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) {
+      const int c0 = ctg[c] * 16 + lg * 4;
+      const bool live = ctg[c] < ct_total && c0 < cout8;
+      biasv[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      slopev[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.bias != nullptr && live) biasv[c] = ((const f32x4*)p.bias)[c0 >> 2];
+      if (p.act == RSA_ACT_PRELU && live) slopev[c] = ((const f32x4*)p.act_vec)[c0 >> 2];
+    }
+    // Epilogues without loads (no residual, no gate): the DMA of tile t+2 is issued right after the barrier that frees tile t's
+    // buffer, BEFORE tile t's epilogue, so it flies under the epilogue and the next tile's MFMAs (two tiles in flight).  Epilogues
+    // that load residuals keep the DMA behind them: their loads would otherwise queue behind it.
+    // With at most 2 accumulator fragments per wave (CTW * NPT <= 2) the residual fragments are cheap to hold: they are loaded right
+    // after the barrier, AHEAD of the DMA, and every layer takes the early path.
+    constexpr bool RES_PREFETCH = CTW * NPT <= 2;
+    const bool early = RES_PREFETCH || (p.res1 == nullptr && p.res2 == nullptr && p.act != RSA_ACT_SPAB_GATE);
     int tile = blockIdx.x;
     int buf = 0;
     issue_tile(tile, buf);
+    if (early && tile + (int)gridDim.x < num_tiles) issue_tile(tile + (int)gridDim.x, 1);
     __syncthreads();  // vmcnt(0) for the DMA + everybody's rows landed
     for (; tile < num_tiles; tile += (int)gridDim.x, buf ^= 1) {
       const int ntile = tile + (int)gridDim.x;
-      if (ntile < num_tiles) issue_tile(ntile, buf ^ 1);
+      if (!early && ntile < num_tiles) issue_tile(ntile, buf ^ 1);
 
       f32x4 acc[NPT][CTW];
 #pragma unroll
@@ -129,6 +149,25 @@ __global__ __launch_bounds__(GK_WAVES * 64, 2) void gemm_k1_kernel(const rsa_con
       }
 
       __syncthreads();  // next tile's rows have landed (vmcnt(0) also retires the PREVIOUS tile's stores, long done); all waves are done with this buffer
+      f32x4 pre1[RES_PREFETCH ? CTW * NPT : 1], pre2[RES_PREFETCH ? CTW * NPT : 1];
+      if (RES_PREFETCH) {
+        const int n = tile / tiles_img;
+        const int64_t pix0 = (int64_t)(tile - n * tiles_img) * GK_TP;
+#pragma unroll
+        for (int c = 0; c < CTW; ++c)
+#pragma unroll
+          for (int pt = 0; pt < NPT; ++pt) {
+            const int c0 = ctg[c] * 16 + lg * 4;
+            const int64_t pix = pix0 + pt * 16 + li;
+            const bool ok = ctg[c] < ct_total && c0 < (p4 << 2) && pix < HW;
+            const int64_t idx = ((int64_t)n * p4 + (c0 >> 2)) * HW + pix;
+            pre1[c * NPT + pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            pre2[c * NPT + pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p.res1 != nullptr && ok) pre1[c * NPT + pt] = ((const f32x4*)p.res1)[idx];
+            if (p.res2 != nullptr && ok) pre2[c * NPT + pt] = ((const f32x4*)p.res2)[idx];
+          }
+      }
+      if (early && ntile + (int)gridDim.x < num_tiles) issue_tile(ntile + (int)gridDim.x, buf);
       // ---- epilogue of this tile AFTER the barrier, so that its stores are in flight under the next tile's DMA and MFMAs instead
       //      of being drained by this barrier's vmcnt(0): lane owns channels c0..c0+3 of pixel pix0 + 16*pt + li ----
       {
@@ -140,10 +179,8 @@ __global__ __launch_bounds__(GK_WAVES * 64, 2) void gemm_k1_kernel(const rsa_con
           if (ctg[c] >= ct_total || cbase >= cout8) continue;
           const int c0 = cbase + lg * 4;
           if (c0 >= cout8) continue;
-          f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-          if (p.bias != nullptr) bias = ((const f32x4*)p.bias)[c0 >> 2];
-          f32x4 slope = {0.f, 0.f, 0.f, 0.f};
-          if (p.act == RSA_ACT_PRELU) slope = ((const f32x4*)p.act_vec)[c0 >> 2];
+          const f32x4 bias = biasv[c];
+          const f32x4 slope = slopev[c];
           const bool has_f32grp = c0 < (p4 << 2);
           const int64_t f32row = ((int64_t)n * p4 + (c0 >> 2)) * HW;
           const int64_t outrow = (int64_t)n * p.out_batch_stride + (int64_t)(p.out_plane_off + (c0 >> 3)) * p.out_plane_stride;
@@ -156,20 +193,21 @@ __global__ __launch_bounds__(GK_WAVES * 64, 2) void gemm_k1_kernel(const rsa_con
             for (int r = 0; r < 4; ++r) v[r] = acc[pt][c][r] + bias[r];
             if (p.act == RSA_ACT_SPAB_GATE) {
               f32x4 rr = {0.f, 0.f, 0.f, 0.f};
-              if (has_f32grp) rr = ((const f32x4*)p.res1)[f32row + pix];
+              if (RES_PREFETCH) rr = pre1[c * NPT + pt];
+              else if (has_f32grp) rr = ((const f32x4*)p.res1)[f32row + pix];
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = (v[r] + rr[r]) * (1.f / (1.f + expf(-v[r])) - 0.5f);
             } else {
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = (p.act == RSA_ACT_GELU) ? act_apply<AC_GELU>(v[r], p.act, 0.f) : act_apply<AC_LINEAR>(v[r], p.act, p.act == RSA_ACT_PRELU ? slope[r] : p.act_param);
               if (p.res1 != nullptr && has_f32grp) {
-                const f32x4 rr = ((const f32x4*)p.res1)[f32row + pix];
+                const f32x4 rr = RES_PREFETCH ? pre1[c * NPT + pt] : ((const f32x4*)p.res1)[f32row + pix];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + rr[r];
               }
             }
             if (p.res2 != nullptr && has_f32grp) {
-              const f32x4 rr = ((const f32x4*)p.res2)[f32row + pix];
+              const f32x4 rr = RES_PREFETCH ? pre2[c * NPT + pt] : ((const f32x4*)p.res2)[f32row + pix];
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = v[r] * p.beta + rr[r];
             }
