@@ -172,10 +172,35 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
     // stores the FULL unit of pixel-tile 2k and lane lg-odd the full unit of pixel-tile 2k+1: 16-byte stores, 512 contiguous
     // bytes per plane and instruction instead of two half-filled 256-byte runs (the 8-byte form was store-issue bound:
     // profiles/r01_l_ab_epilogue.txt)
+    // residual fragments are fetched ONE PAIR AHEAD: pair pp+1's loads are issued before pair pp's stores, so they never queue
+    // behind a store of this epilogue (vmcnt retires in order and counts stores)
+    f32x4 nr1[2], nr2[2];
+    auto fetch_res = [&](int pp) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int pt = pp * 2 + e;
+        const bool okl = pvalid_of(pt) && cvalid && has_f32grp;
+        const uint32_t foff = (f32lane + lpix_of(pt)) * 16u;
+        nr1[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        nr2[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.res1 != nullptr && okl) nr1[e] = *(const f32x4*)(r1b + foff);
+        if (p.res2 != nullptr && okl) nr2[e] = *(const f32x4*)(r2b + foff);
+      }
+    };
+    if (OUTK == 0) fetch_res(0);
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
       float v[2][4];
       bool ok[2];
+      f32x4 cr1[2], cr2[2];
+      if (OUTK == 0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          cr1[e] = nr1[e];
+          cr2[e] = nr2[e];
+        }
+        if (pp + 1 < 4) fetch_res(pp + 1);
+      }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int pt = pp * 2 + e;
@@ -185,8 +210,7 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
         if (OUTK == 0) {
           const uint32_t foff = (f32lane + lpix_of(pt)) * 16u;
           if (AC == AC_GATE) {
-            f32x4 rr = {0.f, 0.f, 0.f, 0.f};
-            if (ok[e] && has_f32grp) rr = *(const f32x4*)(r1b + foff);
+            const f32x4 rr = cr1[e];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float sg = 1.f / (1.f + expf(-v[e][r]));
@@ -196,13 +220,13 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[e][r] = act_apply<AC>(v[e][r], p.act, p.act == RSA_ACT_PRELU ? slope[r] : p.act_param);
             if (p.res1 != nullptr && has_f32grp && ok[e]) {
-              const f32x4 rr = *(const f32x4*)(r1b + foff);
+              const f32x4 rr = cr1[e];
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[e][r] = v[e][r] * p.alpha + rr[r];
             }
           }
           if (p.res2 != nullptr && has_f32grp && ok[e]) {
-            const f32x4 rr = *(const f32x4*)(r2b + foff);
+            const f32x4 rr = cr2[e];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[e][r] = v[e][r] * p.beta + rr[r];
           }
