@@ -148,6 +148,28 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
     if (p.act == RSA_ACT_PRELU && live) slopev[ct] = ((const f32x4*)p.act_vec)[c0 >> 2];  // per-channel PReLU slopes, same padding
   }
 
+  // Residual fragments are fetched ONE STEP AHEAD (a step = one pixel-tile pair of one cout tile): the loads of step s+1 are issued
+  // before the stores of step s, so they never queue behind a store of this epilogue (vmcnt retires in order and counts stores).
+  f32x4 nr1[2], nr2[2];
+  auto fetch_res = [&](int ct, int pp) {
+    const int cbase = (ctile0 + ct) * 16;
+    const int c0 = cbase + lg * 4;
+    const bool cok = (wct * CTW + ct < NCT) && c0 < cout8 && c0 < (p4 << 2);
+    const char* r1b = (const char*)p.res1 + (((int64_t)n * p4 + (cbase >> 2)) * HW + pix0) * 16;
+    const char* r2b = (const char*)p.res2 + (((int64_t)n * p4 + (cbase >> 2)) * HW + pix0) * 16;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int pt = pp * 2 + e;
+      const bool okl = pvalid_of(pt) && cok;
+      const uint32_t foff = ((uint32_t)lg * (uint32_t)HW + lpix_of(pt)) * 16u;
+      nr1[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      nr2[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.res1 != nullptr && okl) nr1[e] = *(const f32x4*)(r1b + foff);
+      if (p.res2 != nullptr && okl) nr2[e] = *(const f32x4*)(r2b + foff);
+    }
+  };
+  if (OUTK == 0) fetch_res(0, 0);
+
 #pragma unroll
   for (int ct = 0; ct < CTW; ++ct) {
     if (wct * CTW + ct >= NCT) break;
@@ -159,8 +181,6 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
     const bool cvalid = c0 < cout8;
     const bool has_f32grp = c0 < (p4 << 2);
     // uniform bases for this cout tile
-    const char* r1b = (const char*)p.res1 + (((int64_t)n * p4 + (cbase >> 2)) * HW + pix0) * 16;
-    const char* r2b = (const char*)p.res2 + (((int64_t)n * p4 + (cbase >> 2)) * HW + pix0) * 16;
     char* f32b = (char*)p.out_f32 + (((int64_t)n * p4 + (cbase >> 2)) * HW + pix0) * 16;
     const int64_t ounit0 = (int64_t)n * p.out_batch_stride + (int64_t)(p.out_plane_off + (cbase >> 3)) * p.out_plane_stride + pix0;
     char* ohb = (char*)p.out_hi + ounit0 * 16;
@@ -172,22 +192,6 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
     // stores the FULL unit of pixel-tile 2k and lane lg-odd the full unit of pixel-tile 2k+1: 16-byte stores, 512 contiguous
     // bytes per plane and instruction instead of two half-filled 256-byte runs (the 8-byte form was store-issue bound:
     // profiles/r01_l_ab_epilogue.txt)
-    // residual fragments are fetched ONE PAIR AHEAD: pair pp+1's loads are issued before pair pp's stores, so they never queue
-    // behind a store of this epilogue (vmcnt retires in order and counts stores)
-    f32x4 nr1[2], nr2[2];
-    auto fetch_res = [&](int pp) {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int pt = pp * 2 + e;
-        const bool okl = pvalid_of(pt) && cvalid && has_f32grp;
-        const uint32_t foff = (f32lane + lpix_of(pt)) * 16u;
-        nr1[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        nr2[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (p.res1 != nullptr && okl) nr1[e] = *(const f32x4*)(r1b + foff);
-        if (p.res2 != nullptr && okl) nr2[e] = *(const f32x4*)(r2b + foff);
-      }
-    };
-    if (OUTK == 0) fetch_res(0);
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
       float v[2][4];
@@ -199,7 +203,10 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
           cr1[e] = nr1[e];
           cr2[e] = nr2[e];
         }
-        if (pp + 1 < 4) fetch_res(pp + 1);
+        if (pp + 1 < 4)
+          fetch_res(ct, pp + 1);
+        else if (ct + 1 < CTW)
+          fetch_res(ct + 1, 0);
       }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
