@@ -361,6 +361,13 @@ typedef struct rsa_aim_params {
 } rsa_aim_params;
 int rsa_aim_combine(const rsa_aim_params* p, void* stream);
 
+/* 8-bit images either side of the path (the reference leaves both steps to its callers):
+ *   rsa_image_u8_to_nchw   uint8 [N][H][W][C] (interleaved, as image decoders deliver it) -> float [N][C][H][W], v / 255
+ *   rsa_nchw_to_image_u8   float [N][C][H][W] -> uint8 [N][H][W][C], round-half-even(clamp(v, 0, 1) * 255)  (torch: (y.clamp(0,1)*255).round())
+ * dtype = rsa_dtype of the float tensor. */
+int rsa_image_u8_to_nchw(const uint8_t* img, int32_t batch, int32_t H, int32_t W, int32_t C, void* out, int32_t dtype, void* stream);
+int rsa_nchw_to_image_u8(const void* x, int32_t dtype, int32_t batch, int32_t C, int32_t H, int32_t W, uint8_t* img, void* stream);
+
 /* version / errors */
 int rsa_version(void);
 const char* rsa_last_error_string(void);

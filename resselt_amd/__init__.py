@@ -36,6 +36,13 @@ def load_from_state_dict(state_dict: Mapping[str, object]):
     return internal_registry.load_from_state_dict(state_dict)
 
 
+def upscale(model, image, **kwargs):
+    """uint8 [H, W, C] / [N, H, W, C] GPU image in, upscaled uint8 image out (see ``resselt_amd.tiling.upscale``).  Not part of the reference API."""
+    from .tiling import upscale as _upscale
+
+    return _upscale(model, image, **kwargs)
+
+
 __all__ = [
     'add',
     'get',
@@ -46,4 +53,5 @@ __all__ = [
     'KeyCondition',
     'ModelMetadata',
     'Registry',
+    'upscale',
 ]

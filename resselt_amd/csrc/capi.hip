@@ -78,6 +78,41 @@ __global__ void nchw_to_planes_kernel(const void* x, int dtype, int batch, int C
   }
 }
 
+// uint8 HWC image <-> float NCHW tensor: one thread per pixel (all channels), so image bytes move as C-byte runs and every
+// tensor plane is read / written with consecutive lanes on consecutive pixels
+__global__ void image_u8_to_nchw_kernel(const uint8_t* img, int batch, int H, int W, int C, void* out, int dtype) {
+  const int64_t HW = (int64_t)H * W;
+  const int64_t total = (int64_t)batch * HW;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = idx / HW, pix = idx - n * HW;
+    for (int c = 0; c < C; ++c) {
+      const float v = (float)img[idx * C + c] / 255.f;  // a true division: bit-identical to torch's img.float() / 255
+      const int64_t o = (n * C + c) * HW + pix;
+      if (dtype == RSA_F32)
+        ((float*)out)[o] = v;
+      else if (dtype == RSA_F16)
+        ((_Float16*)out)[o] = (_Float16)v;
+      else
+        ((__bf16*)out)[o] = (__bf16)v;
+    }
+  }
+}
+
+__global__ void nchw_to_image_u8_kernel(const void* x, int dtype, int batch, int C, int H, int W, uint8_t* img) {
+  const int64_t HW = (int64_t)H * W;
+  const int64_t total = (int64_t)batch * HW;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = idx / HW, pix = idx - n * HW;
+    for (int c = 0; c < C; ++c) {
+      const int64_t i = (n * C + c) * HW + pix;
+      float v = dtype == RSA_F32 ? ((const float*)x)[i] : dtype == RSA_F16 ? (float)((const _Float16*)x)[i] : (float)((const __bf16*)x)[i];
+      v = fminf(fmaxf(v, 0.f), 1.f);  // NaN -> 0, like clamp followed by an integer cast of 0
+      img[idx * C + c] = (uint8_t)rintf(v * 255.f);
+    }
+  }
+}
+
+
 __global__ void planes_to_nchw_kernel(const void* hi, const void* lo, int64_t plane_stride, int64_t batch_stride, int batch, int C, int H,
                                       int W, float* out) {
   const int64_t HW = (int64_t)H * W;
@@ -169,3 +204,21 @@ int rsa_planes_to_nchw(const void* hi, const void* lo, int64_t plane_stride, int
 }
 
 }  // extern "C"
+
+int rsa_image_u8_to_nchw(const uint8_t* img, int32_t batch, int32_t H, int32_t W, int32_t C, void* out, int32_t dtype, void* stream) {
+  if (img == nullptr || out == nullptr || batch < 1 || H < 1 || W < 1 || C < 1) return rsa::set_error(RSA_E_ARG, "image_u8_to_nchw: bad argument");
+  if (dtype < RSA_F32 || dtype > RSA_BF16) return rsa::set_error(RSA_E_ARG, "image_u8_to_nchw: bad dtype");
+  hipLaunchKernelGGL(rsa::image_u8_to_nchw_kernel, dim3(rsa::grid_for((int64_t)batch * H * W, 256)), dim3(256), 0, (hipStream_t)stream, img, batch, H,
+                     W, C, out, dtype);
+  const hipError_t rc = hipGetLastError();
+  return rc ? rsa::set_error(rc, "image_u8_to_nchw: launch failed") : RSA_OK;
+}
+
+int rsa_nchw_to_image_u8(const void* x, int32_t dtype, int32_t batch, int32_t C, int32_t H, int32_t W, uint8_t* img, void* stream) {
+  if (x == nullptr || img == nullptr || batch < 1 || H < 1 || W < 1 || C < 1) return rsa::set_error(RSA_E_ARG, "nchw_to_image_u8: bad argument");
+  if (dtype < RSA_F32 || dtype > RSA_BF16) return rsa::set_error(RSA_E_ARG, "nchw_to_image_u8: bad dtype");
+  hipLaunchKernelGGL(rsa::nchw_to_image_u8_kernel, dim3(rsa::grid_for((int64_t)batch * H * W, 256)), dim3(256), 0, (hipStream_t)stream, x, dtype, batch,
+                     C, H, W, img);
+  const hipError_t rc = hipGetLastError();
+  return rc ? rsa::set_error(rc, "nchw_to_image_u8: launch failed") : RSA_OK;
+}

@@ -277,6 +277,8 @@ EXPORTS = (
     'rsa_channel_gate_workspace_bytes',
     'rsa_channel_gate',
     'rsa_aim_combine',
+    'rsa_image_u8_to_nchw',
+    'rsa_nchw_to_image_u8',
 )
 
 
@@ -335,6 +337,10 @@ def load() -> C.CDLL:
     lib.rsa_plane_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
                                     C.c_void_p]  # fmt: skip
     lib.rsa_plane_stats.restype = C.c_int
+    lib.rsa_image_u8_to_nchw.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.rsa_image_u8_to_nchw.restype = C.c_int
+    lib.rsa_nchw_to_image_u8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.rsa_nchw_to_image_u8.restype = C.c_int
     _lib = lib
     return lib
 

@@ -187,3 +187,31 @@ def planes_to_nchw(p: Planes, channels: int) -> torch.Tensor:
         'rsa_planes_to_nchw',
     )  # fmt: skip
     return out
+
+
+def image_u8_to_nchw(img: torch.Tensor, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """uint8 [N, H, W, C] image batch (or [H, W, C]) on the GPU -> float [N, C, H, W] in [0, 1] (rsa_image_u8_to_nchw)."""
+    require_cuda(img, 'image_u8_to_nchw')
+    if img.dtype != torch.uint8 or img.dim() not in (3, 4):
+        raise TypeError(f'expected a uint8 [N, H, W, C] or [H, W, C] image, got {img.dtype} {tuple(img.shape)}')
+    if img.dim() == 3:
+        img = img.unsqueeze(0)
+    img = img.contiguous()
+    n, h, w, c = img.shape
+    out = torch.empty((n, c, h, w), dtype=dtype, device=img.device)
+    L.check(L.load().rsa_image_u8_to_nchw(img.data_ptr(), n, h, w, c, out.data_ptr(), rsa_dtype(dtype), C.c_void_p(current_stream_ptr(img.device))),
+            'rsa_image_u8_to_nchw')  # fmt: skip
+    return out
+
+
+def nchw_to_image_u8(x: torch.Tensor) -> torch.Tensor:
+    """float [N, C, H, W] -> uint8 [N, H, W, C], ``(x.clamp(0, 1) * 255).round()`` (rsa_nchw_to_image_u8)."""
+    require_cuda(x, 'nchw_to_image_u8')
+    if x.dim() != 4:
+        raise ValueError(f'expected a [N, C, H, W] tensor, got shape {tuple(x.shape)}')
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    out = torch.empty((n, h, w, c), dtype=torch.uint8, device=x.device)
+    L.check(L.load().rsa_nchw_to_image_u8(x.data_ptr(), rsa_dtype(x.dtype), n, c, h, w, out.data_ptr(), C.c_void_p(current_stream_ptr(x.device))),
+            'rsa_nchw_to_image_u8')  # fmt: skip
+    return out

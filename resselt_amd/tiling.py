@@ -101,6 +101,32 @@ def upscale_tiled(model, x: torch.Tensor, scale: int, tile: tuple[int, int], hal
     return out
 
 
+def upscale(model, image: torch.Tensor, tile: tuple[int, int] | None = None, halo: int = 32, align: int = 1,
+            dtype: torch.dtype = torch.float16, scale: int | None = None) -> torch.Tensor:
+    """uint8 image in, uint8 image out: ``image`` is [H, W, C] or [N, H, W, C] uint8 on the GPU (what an image decoder delivers).
+
+    ``/255`` and the NHWC->NCHW transpose run in one kernel, the model runs on ``dtype`` tensors (whole image, or ``tile``-sized tiles
+    with ``halo`` pixels of context when the image is larger than ``tile``), and ``clamp(0, 1) * 255`` + round-half-even + NCHW->NHWC
+    run in one kernel.  The reference leaves both conversions and the tiling to its callers.
+    ``align``: SwinIR-family models want tile origins on a window multiple.
+    """
+    from .engine import ops
+
+    squeeze = image.dim() == 3
+    x = ops.image_u8_to_nchw(image, dtype)
+    if scale is None:
+        scale = model.parameters_info.upscale
+        if not isinstance(scale, int):
+            raise ValueError('this model has several output scales: pass scale=')
+    _, _, h, w = x.shape
+    if tile is None or (h <= tile[0] and w <= tile[1]):
+        y = model(x)
+    else:
+        y = upscale_tiled(model, x, scale, tile, halo, align)
+    out = ops.nchw_to_image_u8(y)
+    return out[0] if squeeze else out
+
+
 class TileParallel:
     """``TileParallel(model, scale)(x)``: every rank of the process group upscales its share of the tiles of ``x`` and
     all ranks return the complete upscaled image.

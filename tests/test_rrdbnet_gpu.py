@@ -115,3 +115,29 @@ def test_rrdbnet_tiled_driver_on_gpu(device):
     assert tiled.shape == full.shape and (tiled - full).abs().max().item() <= 1e-4
     one = TileParallel(m, scale=4, halo=40, grid=(2, 2))(x)  # world size 1: all four tiles on this GPU
     assert (one - full).abs().max().item() <= 1e-4
+
+
+def test_uint8_image_round_trip_and_upscale_helper(device):
+    """uint8 HWC images either side of the path: conversion kernels bit-exact vs torch, helper == manual pipeline."""
+    from resselt_amd.engine import ops
+    from resselt_amd.tiling import upscale
+
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, (2, 37, 53, 3), generator=g, dtype=torch.uint8)
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        x = ops.image_u8_to_nchw(img.to(device), dt)
+        ref = (img.permute(0, 3, 1, 2).float() / 255).to(dt)
+        assert torch.equal(x.cpu(), ref)
+    y = torch.randn((2, 3, 20, 31), generator=g) * 0.7 + 0.5
+    y[0, 0, 0, :4] = torch.tensor([0.5 / 255, 1.5 / 255, 2.5 / 255, float('nan')])  # ties round to even; NaN -> 0
+    out = ops.nchw_to_image_u8(y.to(device))
+    ref = (torch.nan_to_num(y, nan=0.0).clamp(0, 1) * 255).round().to(torch.uint8).permute(0, 2, 3, 1)
+    assert torch.equal(out.cpu(), ref)
+    sd = synth.rrdbnet_state_dict(nb=2, scale=4, seed=9)
+    m = resselt_amd.load_from_state_dict(dict(sd)).to(device)
+    one = upscale(m, img[0].to(device), dtype=torch.float32)
+    assert one.shape == (37 * 4, 53 * 4, 3) and one.dtype == torch.uint8
+    manual = ops.nchw_to_image_u8(m(ops.image_u8_to_nchw(img[:1].to(device))))[0]
+    assert torch.equal(one, manual)
+    tiled = upscale(m, img[0].to(device), tile=(24, 32), halo=16, dtype=torch.float32)
+    assert (tiled.int() - one.int()).abs().max().item() <= 1  # nb=2: receptive field < halo, so at most a rounding tie
