@@ -400,3 +400,77 @@ def spanpp_state_dict(num_in_ch=3, feature_channels=48, scale_list=(1, 2, 3, 4),
     _conv(sd, f'upsampler.query_kernel.{2 * latent_layers}', 3, implicit_dim, 1, seed)
     sd['MetaIGConv'] = torch.tensor(sorted(set(scale_list)), dtype=torch.uint8)
     return sd
+
+
+def hat_rpi(window: int, overlap_ratio: float):
+    """The two registered index buffers of HAT (archs/hat/arch.py:987-1034): self-attention and overlapping cross-attention."""
+    co = torch.stack(torch.meshgrid([torch.arange(window), torch.arange(window)], indexing='ij')).flatten(1)
+    rel = (co[:, :, None] - co[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += window - 1
+    rel[:, :, 1] += window - 1
+    rel[:, :, 0] *= 2 * window - 1
+    sa = rel.sum(-1)
+    ext = window + int(overlap_ratio * window)
+    ce = torch.stack(torch.meshgrid([torch.arange(ext), torch.arange(ext)], indexing='ij')).flatten(1)
+    rel = (ce[:, None, :] - co[:, :, None]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += window - ext + 1
+    rel[:, :, 1] += window - ext + 1
+    rel[:, :, 0] *= window + ext - 1
+    return sa, rel.sum(-1)
+
+
+def hat_state_dict(in_chans=3, embed_dim=60, depths=(2, 2), num_heads=(6, 6), window=8, compress_ratio=3, squeeze_factor=30, overlap_ratio=0.5,
+                   mlp_ratio=2.0, upscale=2, num_feat=64, resi='1conv', seed=0):  # fmt: skip
+    """Keys of the reference HAT module (archs/hat/arch.py:798-1110) incl. its two index buffers."""
+    sd: OrderedDict = OrderedDict()
+    C = embed_dim
+    hidden = int(C * mlp_ratio)
+    ext = window + int(overlap_ratio * window)
+
+    def lin(name, cout, cin):
+        sd[f'{name}.weight'] = synth_tensor(f'{name}.weight', (cout, cin), cin, seed)
+        sd[f'{name}.bias'] = synth_tensor(f'{name}.bias', (cout,), cin, seed)
+
+    def ln(name):
+        sd[f'{name}.weight'] = 1.0 + synth_tensor(f'{name}.weight', (C,), 16, seed)
+        sd[f'{name}.bias'] = synth_tensor(f'{name}.bias', (C,), 16, seed)
+
+    sd['relative_position_index_SA'], sd['relative_position_index_OCA'] = hat_rpi(window, overlap_ratio)
+    _conv(sd, 'conv_first', C, in_chans, 3, seed)
+    ln('patch_embed.norm')
+    for i, depth in enumerate(depths):
+        g = f'layers.{i}.residual_group'
+        for j in range(depth):
+            b = f'{g}.blocks.{j}'
+            ln(f'{b}.norm1')
+            sd[f'{b}.attn.relative_position_bias_table'] = synth_tensor(f'{b}.rpb', ((2 * window - 1) ** 2, num_heads[i]), 4, seed)
+            lin(f'{b}.attn.qkv', 3 * C, C)
+            lin(f'{b}.attn.proj', C, C)
+            _conv(sd, f'{b}.conv_block.cab.0', C // compress_ratio, C, 3, seed)
+            _conv(sd, f'{b}.conv_block.cab.2', C, C // compress_ratio, 3, seed)
+            _conv(sd, f'{b}.conv_block.cab.3.attention.1', C // squeeze_factor, C, 1, seed)
+            _conv(sd, f'{b}.conv_block.cab.3.attention.3', C, C // squeeze_factor, 1, seed)
+            ln(f'{b}.norm2')
+            lin(f'{b}.mlp.fc1', hidden, C)
+            lin(f'{b}.mlp.fc2', C, hidden)
+        o = f'{g}.overlap_attn'
+        ln(f'{o}.norm1')
+        lin(f'{o}.qkv', 3 * C, C)
+        sd[f'{o}.relative_position_bias_table'] = synth_tensor(f'{o}.rpb', ((window + ext - 1) ** 2, num_heads[i]), 4, seed)
+        lin(f'{o}.proj', C, C)
+        ln(f'{o}.norm2')
+        lin(f'{o}.mlp.fc1', hidden, C)
+        lin(f'{o}.mlp.fc2', C, hidden)
+        if resi == '1conv':
+            _conv(sd, f'layers.{i}.conv', C, C, 3, seed)
+    ln('norm')
+    if resi == '1conv':
+        _conv(sd, 'conv_after_body', C, C, 3, seed)
+    _conv(sd, 'conv_before_upsample.0', num_feat, C, 3, seed)
+    if upscale == 3:
+        _conv(sd, 'upsample.0', 9 * num_feat, num_feat, 3, seed)
+    else:
+        for u in range({1: 0, 2: 1, 4: 2, 8: 3}[upscale]):
+            _conv(sd, f'upsample.{2 * u}', 4 * num_feat, num_feat, 3, seed)
+    _conv(sd, 'conv_last', in_chans, num_feat, 3, seed)
+    return sd

@@ -25,11 +25,11 @@ def synth_state_dict(meta):
     from resselt_amd.utils import synth
 
     kw = dict(meta['synth'])
-    for k in ('blocks', 'depth', 'num_heads', 'split_size', 'scale_list'):
+    for k in ('blocks', 'depth', 'depths', 'num_heads', 'split_size', 'scale_list'):
         if k in kw:
             kw[k] = tuple(kw[k])
     fn = {'esrgan': synth.rrdbnet_state_dict, 'spanplus': synth.spanplus_state_dict, 'span': synth.span_state_dict,
-          'swinir': getattr(synth, 'swinir_state_dict', None), 'compact': synth.compact_state_dict, 'dat': getattr(synth, 'dat_state_dict', None), 'spanpp': getattr(synth, 'spanpp_state_dict', None)}[meta['arch']]  # fmt: skip
+          'swinir': getattr(synth, 'swinir_state_dict', None), 'compact': synth.compact_state_dict, 'dat': getattr(synth, 'dat_state_dict', None), 'spanpp': getattr(synth, 'spanpp_state_dict', None), 'hat': getattr(synth, 'hat_state_dict', None)}[meta['arch']]  # fmt: skip
     return fn(seed=meta['seed'], **kw)
 
 
@@ -58,6 +58,10 @@ def oracle_forward(meta, sd, x):
         from oracle.spanpp import spanpp_forward
 
         return spanpp_forward(sd, x, meta.get('scale'))
+    if meta['arch'] == 'hat':
+        from oracle.hat import hat_forward
+
+        return hat_forward(sd, x)
     if meta['arch'] == 'dat':
         from oracle.dat import dat_forward
 

@@ -214,6 +214,23 @@ def spanpp_cases():
         save(name, dict(arch='spanpp', synth=kw, seed=seed, scale=scale, metadata=meta, mode='eval'), x=x, y=y)
 
 
+def hat_cases():
+    """HAT end to end, eval mode (DropPath 0.1 is random in the train-mode module the loader returns)."""
+    cases = [
+        ('hat_x2_e60_w8_d2_2_20x27', dict(), (1, 3, 20, 27), 101),
+        ('hat_x4_e180_w16_d2_b2_32x48', dict(embed_dim=180, depths=(2,), num_heads=(6,), window=16, upscale=4), (2, 3, 32, 48), 102),
+        ('hat_x3_e96_w8_d3_identity_25x40', dict(embed_dim=96, depths=(3,), num_heads=(6,), upscale=3, mlp_ratio=4.0, resi='identity'), (1, 3, 25, 40), 103),
+        ('hat_x2_e180_w16_d2_2_50x70', dict(embed_dim=180, depths=(2, 2), num_heads=(6, 6), window=16, upscale=2), (1, 3, 50, 70), 104),
+    ]
+    for name, kw, shape, seed in cases:
+        sd = synth.hat_state_dict(seed=seed, **kw)
+        model = resselt.load_from_state_dict(dict(sd)).eval()
+        x = synth.synth_input(shape, seed)
+        y = model(x)
+        kw = {k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()}
+        save(name, dict(arch='hat', synth=kw, seed=seed, metadata=meta_of(model), mode='eval'), x=x, y=y)
+
+
 def registry_cases():
     """Detection order facts: which reference architecture claims each synthetic checkpoint."""
     claims = {}
@@ -225,6 +242,7 @@ def registry_cases():
         ('compact', synth.compact_state_dict(num_conv=2)),
         ('swinir', synth.swinir_state_dict()),
         ('dat', synth.dat_state_dict()),
+        ('hat', synth.hat_state_dict()),
         ('spanpp', synth.spanpp_state_dict(feature_channels=16, implicit_dim=32, latent_layers=1)),
     ):
         for arch in resselt.archs.internal_registry.store.values():
@@ -235,7 +253,7 @@ def registry_cases():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['esrgan', 'blocks', 'span', 'compact', 'registry', 'swinir', 'dat', 'spanpp']
+    which = sys.argv[1:] or ['esrgan', 'blocks', 'span', 'compact', 'registry', 'swinir', 'dat', 'spanpp', 'hat']
     if 'esrgan' in which:
         esrgan_cases()
     if 'blocks' in which:
@@ -248,6 +266,8 @@ if __name__ == '__main__':
         dat_cases()
     if 'spanpp' in which:
         spanpp_cases()
+    if 'hat' in which:
+        hat_cases()
     if 'registry' in which:
         registry_cases()
     if 'swinir' in which:
