@@ -252,6 +252,11 @@ typedef struct rsa_rect_attn_params {
   void* out_lo;
   int64_t out_plane_stride;
   int64_t out_batch_stride;
+  /* Cross-window mode (0 = off): keys / values come from the kwin_h x kwin_w window that starts kpad pixels up-left of the query
+   * window, zeros outside the map -- OCAB of HAT (reference archs/hat/arch.py:403-470: nn.Unfold with padding).  bias_frag is then
+   * [heads][QT][KT][64][16] with QT = ceil(win_h*win_w / 32), KT = ceil(kwin_h*kwin_w / 32).  No shift, Hp == H, Wp == W. */
+  int32_t kwin_h, kwin_w;
+  int32_t kpad_h, kpad_w;
 } rsa_rect_attn_params;
 int rsa_rect_attention(const rsa_rect_attn_params* p, void* stream);
 
@@ -328,6 +333,7 @@ typedef struct rsa_channel_gate_params {
   const float* b2;           /* [C] */
   float* workspace;
   float* gate;               /* [batch][C] */
+  int32_t relu;              /* hidden activation: 0 = GELU (DAT), 1 = ReLU (the RCAN-style channel attention of HAT's CAB, archs/hat/arch.py:28-35) */
 } rsa_channel_gate_params;
 int64_t rsa_channel_gate_workspace_bytes(int32_t batch, int32_t H, int32_t W, int32_t planes);
 int rsa_channel_gate(const rsa_channel_gate_params* p, void* stream);
@@ -360,6 +366,11 @@ typedef struct rsa_aim_params {
   int64_t out_batch_stride;
 } rsa_aim_params;
 int rsa_aim_combine(const rsa_aim_params* p, void* stream);
+
+/* out = base + x * gate[b][c] * scale on f32 maps [N][ceil(C/4)][H][W][4], x in split planes; gate rows have 8*ceil(C/8) entries.
+ * HAT's `shortcut + conv_x * conv_scale` with the CAB's channel attention as the gate (reference archs/hat/arch.py:37-39, 345). */
+int rsa_gated_add(const void* x_hi, const void* x_lo, int64_t plane_stride, int64_t batch_stride, int32_t batch, int32_t H, int32_t W, int32_t C,
+                  const float* gate, float scale, const float* base_f32, float* out_f32, void* stream);
 
 /* 8-bit images either side of the path (the reference leaves both steps to its callers):
  *   rsa_image_u8_to_nchw   uint8 [N][H][W][C] (interleaved, as image decoders deliver it) -> float [N][C][H][W], v / 255

@@ -58,8 +58,13 @@ __device__ __forceinline__ bf16x8 pack_bf16(const float (&v)[8]) {
   return r;
 }
 
-// One workgroup (4 waves) = one (window, head).  T = tiles of 32 tokens (window tokens padded to 32*T).
-// K and V of the window are staged once in LDS; wave w then owns query tiles w, w+4.
+// One workgroup (4 waves) = one (window, head).  T = tiles of 32 tokens the LDS images hold.
+//   self mode  (kwin == 0): keys = the window's own tokens (<= 32*T), staged once;
+//   cross mode (kwin > 0) : keys = the (kwin_h x kwin_w) window that starts kpad pixels up-left of the query window (HAT's
+//                           overlapping cross-attention: unfold with zero padding, archs/hat/arch.py:403-470), staged in chunks of
+//                           32*T keys; the flash-style running max / sum / output of a wave's (up to two) query tiles live in
+//                           registers across the chunks.
+// K and V of a chunk are staged once in LDS; wave w owns query tiles w and w + 4.
 template <int PROD, int T>
 __global__ __launch_bounds__(256, 2) void rect_attention_kernel(const rsa_rect_attn_params p) {
   constexpr int NT = 32 * T;
@@ -72,6 +77,11 @@ __global__ __launch_bounds__(256, 2) void rect_attention_kernel(const rsa_rect_a
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntok = p.win_h * p.win_w;
+  const bool cross = p.kwin_h > 0;
+  const int nkey = cross ? p.kwin_h * p.kwin_w : ntok;
+  const int QT = (ntok + 31) >> 5;          // query tiles (<= 8)
+  const int KT = cross ? (nkey + 31) >> 5 : T;  // key tiles in total (self mode: the instantiated T, padded keys carry -1e30 bias)
+  const int QTB = cross ? QT : T;               // query tiles of the bias_frag layout
   const int nwx = p.Wp / p.win_w, nwy = p.Hp / p.win_h;
   const int64_t item = blockIdx.x;
   const int head = (int)(item % p.heads);
@@ -80,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void rect_attention_kernel(const rsa_rect_a
   const int wy = (int)((win / nwx) % nwy);
   const int n = (int)(win / ((int64_t)nwx * nwy));
 
-  // source pixel of window token t: roll(-shift) on the PADDED grid, then partition; tokens that land on padding are zero
+  // source pixel of QUERY token t: roll(-shift) on the PADDED grid, then partition; tokens that land on padding are zero
   auto token_pix = [&](int t, bool& valid) -> int64_t {
     const int ty = t / p.win_w, tx = t - ty * p.win_w;
     int sy = wy * p.win_h + ty + p.shift_h;
@@ -88,6 +98,14 @@ __global__ __launch_bounds__(256, 2) void rect_attention_kernel(const rsa_rect_a
     if (sy >= p.Hp) sy -= p.Hp;
     if (sx >= p.Wp) sx -= p.Wp;
     valid = t < ntok && sy < p.H && sx < p.W;
+    return valid ? (int64_t)sy * p.W + sx : 0;
+  };
+  // source pixel of KEY token t: the query token's in self mode; a pixel of the enlarged window (zero outside the map) in cross mode
+  auto key_pix = [&](int t, bool& valid) -> int64_t {
+    if (!cross) return token_pix(t, valid);
+    const int ky = t / p.kwin_w, kx = t - ky * p.kwin_w;
+    const int sy = wy * p.win_h - p.kpad_h + ky, sx = wx * p.win_w - p.kpad_w + kx;
+    valid = t < nkey && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
     return valid ? (int64_t)sy * p.W + sx : 0;
   };
 
@@ -99,31 +117,6 @@ __global__ __launch_bounds__(256, 2) void rect_attention_kernel(const rsa_rect_a
   const int64_t k_plane0 = (int64_t)(1 * p.heads_total + slot) * 4;
   const int64_t v_plane0 = (int64_t)(2 * p.heads_total + slot) * 4;
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-
-  // ---- stage K and V: thread = token ----
-  if (tid < NT) {
-    bool valid;
-    const int64_t pix = token_pix(tid, valid);
-#pragma unroll
-    for (int pl = 0; pl < 4; ++pl) {
-      bf16x8 kh = zero8, kl = zero8, vh = zero8, vl = zero8;
-      if (valid) {
-        kh = qkv_hi[(k_plane0 + pl) * ps + pix];
-        vh = qkv_hi[(v_plane0 + pl) * ps + pix];
-        if (PROD == 3) {
-          kl = qkv_lo[(k_plane0 + pl) * ps + pix];
-          vl = qkv_lo[(v_plane0 + pl) * ps + pix];
-        }
-      }
-      *(bf16x8*)&s_k[0][tid * KROW + pl * 8] = kh;
-      *(bf16x8*)&s_v[0][tid * 32 + pl * 8] = vh;
-      if (PROD == 3) {
-        *(bf16x8*)&s_k[NHL - 1][tid * KROW + pl * 8] = kl;
-        *(bf16x8*)&s_v[NHL - 1][tid * 32 + pl * 8] = vl;
-      }
-    }
-  }
-  __syncthreads();
 
   const int lr = lane & 31;
   const int lh = lane >> 5;
@@ -138,126 +131,171 @@ __global__ __launch_bounds__(256, 2) void rect_attention_kernel(const rsa_rect_a
     const int rx = gx < p.Wp - p.win_w ? 0 : (gx < p.Wp - p.shift_w ? 1 : 2);
     return ry * 3 + rx;
   };
-  char* out_hi = (char*)p.out_hi + (int64_t)n * p.out_batch_stride * 16;
-  char* out_lo = (p.out_lo != nullptr) ? (char*)p.out_lo + (int64_t)n * p.out_batch_stride * 16 : nullptr;
   typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
-  for (int qt = wave; qt < T; qt += 4) {
-    // ---- Q fragments (B operand): query 32qt + lr, channels 16s + 8lh .. +7 = plane 2s + lh ----
-    bool qvalid;
-    const int64_t qpix = token_pix(32 * qt + lr, qvalid);
-    bf16x8 qh[2], ql[2];
+  // ---- per-wave state of its (up to two) query tiles ----
+  bool qvalid[2];
+  int64_t qpix[2];
+  bf16x8 qh[2][2], ql[2][2];
+  float m[2], l[2];
+  f32x16 ot[2];
+  int rq[2];
+#pragma unroll
+  for (int qi = 0; qi < 2; ++qi) {
+    const int qt = wave + 4 * qi;
+    qpix[qi] = token_pix(32 * qt + lr, qvalid[qi]);
+    if (qt >= QT) qvalid[qi] = false;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      qh[s] = zero8;
-      ql[s] = zero8;
-      if (qvalid) {
-        qh[s] = qkv_hi[(q_plane0 + 2 * s + lh) * ps + qpix];
-        if (PROD == 3) ql[s] = qkv_lo[(q_plane0 + 2 * s + lh) * ps + qpix];
+      // Q fragments (B operand): query 32qt + lr, channels 16s + 8lh .. +7 = plane 2s + lh
+      qh[qi][s] = zero8;
+      ql[qi][s] = zero8;
+      if (qvalid[qi]) {
+        qh[qi][s] = qkv_hi[(q_plane0 + 2 * s + lh) * ps + qpix[qi]];
+        if (PROD == 3) ql[qi][s] = qkv_lo[(q_plane0 + 2 * s + lh) * ps + qpix[qi]];
       }
     }
-    // ---- key tiles, flash style: S^T tile -> + bias / mask -> running max and sum -> P tile -> O^T += V^T P^T ----
-    // accumulator element r of lane (lr, lh): key = 32kt + (r&3) + 8(r>>2) + 4lh, query = 32qt + lr (one query column per lane)
-    const int rq = masked ? region(32 * qt + lr) : 0;
-    float m = -3.0e38f, l = 0.f;
-    f32x16 ot;
+    rq[qi] = masked ? region(32 * qt + lr) : 0;
+    m[qi] = -3.0e38f;
+    l[qi] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ot[r] = 0.f;
-    for (int kt = 0; kt < T; ++kt) {
-      f32x16 a;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) a[r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int off = (32 * kt + lr) * KROW + (2 * s + lh) * 8;
-        const bf16x8 kh = *(const bf16x8*)&s_k[0][off];
-        if (PROD == 3) {
-          const bf16x8 kl = *(const bf16x8*)&s_k[NHL - 1][off];
-          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[s], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[s], a, 0, 0, 0);
-        }
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[s], a, 0, 0, 0);
-      }
-      // + dynamic position bias (pre-gathered, -1e30 on padded keys) + shift mask
-      const f32x4* bf = (const f32x4*)(p.bias_frag + ((((int64_t)head * T + qt) * T + kt) * 64 + lane) * 16);
-      float tm = -3.0e38f;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 b = bf[g];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = g * 4 + e;
-          float v = a[r] + b[e];
-          if (masked) {
-            const int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (region(key) != rq) v += -100.f;
-          }
-          a[r] = v;
-          tm = fmaxf(tm, v);
-        }
-      }
-      tm = fmaxf(tm, __shfl_xor(tm, 32));
-      const float mn = fmaxf(m, tm);
-      const float alpha = expf(m - mn);  // 0 on the first tile
-      m = mn;
-      l *= alpha;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        ot[r] *= alpha;
-        const float e = expf(a[r] - m);
-        a[r] = e;
-        l += e;
-      }
-      // O^T[channel][query] += V^T P^T: A = V^T through transpose reads, B = the P tile straight from the accumulators
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8 vh, vl;
-#pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2) {
-          const int row = 32 * kt + 16 * s + 8 * g2 + 4 * lh + (li16 >> 2);
-          const int col = 16 * (g16 & 1) + 4 * (li16 & 3);
-          const bf16x4 th = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)&s_v[0][row * 32 + col]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) vh[g2 * 4 + e] = th[e];
-          if (PROD == 3) {
-            const bf16x4 tl = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)&s_v[NHL - 1][row * 32 + col]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) vl[g2 * 4 + e] = tl[e];
-          }
-        }
-        float e8[8], r8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e8[j] = a[8 * s + j];
-        const bf16x8 ph = pack_bf16(e8);
-        if (PROD == 3) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) r8[j] = e8[j] - (float)ph[j];
-          const bf16x8 pl = pack_bf16(r8);
-          ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, ot, 0, 0, 0);
-          ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, ot, 0, 0, 0);
-        }
-        ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, ot, 0, 0, 0);
-      }
-    }
-    l += __shfl_xor(l, 32);  // the two halves of a query column share m, so their partial sums just add
-    const float inv_l = 1.f / l;
+    for (int r = 0; r < 16; ++r) ot[qi][r] = 0.f;
+  }
 
-    // ---- normalise and store: lane owns query 32qt + lr, channels 8g + 4lh .. +3 ----
-    if (qvalid) {
+  for (int kt0 = 0; kt0 < KT; kt0 += T) {
+    // ---- stage K and V of key tiles [kt0, kt0 + T): thread = key token ----
+    if (kt0 > 0) __syncthreads();  // everybody is done with the previous chunk
+    if (tid < NT) {
+      bool valid;
+      const int64_t pix = key_pix(32 * kt0 + tid, valid);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4 h, lo4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = ot[g * 4 + e] * inv_l;
-          const __bf16 hb = (__bf16)v;
-          h[e] = hb;
-          lo4[e] = (__bf16)(v - (float)hb);
+      for (int pl = 0; pl < 4; ++pl) {
+        bf16x8 kh = zero8, kl = zero8, vh = zero8, vl = zero8;
+        if (valid) {
+          kh = qkv_hi[(k_plane0 + pl) * ps + pix];
+          vh = qkv_hi[(v_plane0 + pl) * ps + pix];
+          if (PROD == 3) {
+            kl = qkv_lo[(k_plane0 + pl) * ps + pix];
+            vl = qkv_lo[(v_plane0 + pl) * ps + pix];
+          }
         }
-        const int64_t off = (((int64_t)slot * 4 + g) * p.out_plane_stride + qpix) * 16 + lh * 8;
-        *(bf16x4*)(out_hi + off) = h;
-        if (out_lo != nullptr) *(bf16x4*)(out_lo + off) = lo4;
+        *(bf16x8*)&s_k[0][tid * KROW + pl * 8] = kh;
+        *(bf16x8*)&s_v[0][tid * 32 + pl * 8] = vh;
+        if (PROD == 3) {
+          *(bf16x8*)&s_k[NHL - 1][tid * KROW + pl * 8] = kl;
+          *(bf16x8*)&s_v[NHL - 1][tid * 32 + pl * 8] = vl;
+        }
       }
+    }
+    __syncthreads();
+    const int ktn = (KT - kt0 < T) ? KT - kt0 : T;  // key tiles in this chunk
+
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+      const int qt = wave + 4 * qi;
+      if (qt >= QT) break;
+      // ---- key tiles, flash style: S^T tile -> + bias / mask -> running max and sum -> P tile -> O^T += V^T P^T ----
+      // accumulator element r of lane (lr, lh): key = 32kt + (r&3) + 8(r>>2) + 4lh, query = 32qt + lr (one query column per lane)
+      for (int kt = 0; kt < ktn; ++kt) {
+        f32x16 a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int off = (32 * kt + lr) * KROW + (2 * s + lh) * 8;
+          const bf16x8 kh = *(const bf16x8*)&s_k[0][off];
+          if (PROD == 3) {
+            const bf16x8 kl = *(const bf16x8*)&s_k[NHL - 1][off];
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[qi][s], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[qi][s], a, 0, 0, 0);
+          }
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[qi][s], a, 0, 0, 0);
+        }
+        // + position bias (pre-gathered per (query tile, key tile), -1e30 on padded keys) + shift mask
+        const f32x4* bf = (const f32x4*)(p.bias_frag + ((((int64_t)head * QTB + qt) * KT + kt0 + kt) * 64 + lane) * 16);
+        float tm = -3.0e38f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b = bf[g];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = g * 4 + e;
+            float v = a[r] + b[e];
+            if (masked) {
+              const int key = 32 * (kt0 + kt) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              if (region(key) != rq[qi]) v += -100.f;
+            }
+            a[r] = v;
+            tm = fmaxf(tm, v);
+          }
+        }
+        tm = fmaxf(tm, __shfl_xor(tm, 32));
+        const float mn = fmaxf(m[qi], tm);
+        const float alpha = expf(m[qi] - mn);  // 0 on the first tile
+        m[qi] = mn;
+        l[qi] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          ot[qi][r] *= alpha;
+          const float e = expf(a[r] - mn);
+          a[r] = e;
+          l[qi] += e;
+        }
+        // O^T[channel][query] += V^T P^T: A = V^T through transpose reads, B = the P tile straight from the accumulators
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf16x8 vh, vl;
+#pragma unroll
+          for (int g2 = 0; g2 < 2; ++g2) {
+            const int row = 32 * kt + 16 * s + 8 * g2 + 4 * lh + (li16 >> 2);
+            const int col = 16 * (g16 & 1) + 4 * (li16 & 3);
+            const bf16x4 th = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)&s_v[0][row * 32 + col]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vh[g2 * 4 + e] = th[e];
+            if (PROD == 3) {
+              const bf16x4 tl = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)&s_v[NHL - 1][row * 32 + col]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) vl[g2 * 4 + e] = tl[e];
+            }
+          }
+          float e8[8], r8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e8[j] = a[8 * s + j];
+          const bf16x8 ph = pack_bf16(e8);
+          if (PROD == 3) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r8[j] = e8[j] - (float)ph[j];
+            const bf16x8 pl = pack_bf16(r8);
+            ot[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, ot[qi], 0, 0, 0);
+            ot[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, ot[qi], 0, 0, 0);
+          }
+          ot[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, ot[qi], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- normalise and store: lane owns query 32qt + lr, channels 8g + 4lh .. +3 ----
+  char* out_hi = (char*)p.out_hi + (int64_t)n * p.out_batch_stride * 16;
+  char* out_lo = (p.out_lo != nullptr) ? (char*)p.out_lo + (int64_t)n * p.out_batch_stride * 16 : nullptr;
+#pragma unroll
+  for (int qi = 0; qi < 2; ++qi) {
+    const float lsum = l[qi] + __shfl_xor(l[qi], 32);  // the two halves of a query column share m, so their partial sums just add
+    if (!qvalid[qi]) continue;
+    const float inv_l = 1.f / lsum;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 h, lo4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = ot[qi][g * 4 + e] * inv_l;
+        const __bf16 hb = (__bf16)v;
+        h[e] = hb;
+        lo4[e] = (__bf16)(v - (float)hb);
+      }
+      const int64_t off = (((int64_t)slot * 4 + g) * p.out_plane_stride + qpix[qi]) * 16 + lh * 8;
+      *(bf16x4*)(out_hi + off) = h;
+      if (out_lo != nullptr) *(bf16x4*)(out_lo + off) = lo4;
     }
   }
 }
@@ -510,7 +548,7 @@ __global__ __launch_bounds__(256) void channel_gate_kernel(const rsa_channel_gat
     const int k = threadIdx.x;
     float s = p.b1[k];
     for (int c = 0; c < C; ++c) s += p.w1[(int64_t)k * C + c] * s_mean[c];
-    s_hid[k] = gelu_erf(s);
+    s_hid[k] = p.relu ? fmaxf(s, 0.f) : gelu_erf(s);
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -571,6 +609,32 @@ __global__ __launch_bounds__(256) void aim_kernel(const rsa_aim_params p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ gated add
+// out[b][c][p] = base[b][c][p] + x[b][c][p] * gate[b][c] * scale on f32 maps (HAT: shortcut + CAB(x) * 0.01, arch.py:345, with the
+// channel attention of the CAB as `gate`); thread = (pixel, plane of 8 channels); grid (ceil(HW/256), planes, batch)
+__global__ __launch_bounds__(256) void gated_add_kernel(const bf16x8* x_hi, const bf16x8* x_lo, int64_t plane_stride, int64_t batch_stride, int64_t HW,
+                                                        int C, const float* gate, float scale, const f32x4* base, f32x4* out) {
+  const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int pl = blockIdx.y, n = blockIdx.z;
+  if (pix >= HW) return;
+  const int p4 = (C + 3) >> 2;
+  float v[8];
+  unit_f32(x_hi + (int64_t)n * batch_stride + (int64_t)pl * plane_stride, x_lo ? x_lo + (int64_t)n * batch_stride + (int64_t)pl * plane_stride : nullptr,
+           pix, v);
+  const float* g = gate + (int64_t)n * (((C + 7) >> 3) << 3) + pl * 8;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int grp = pl * 2 + half;
+    if (grp >= p4) continue;
+    const int64_t i = ((int64_t)n * p4 + grp) * HW + pix;
+    const f32x4 b = base[i];
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = b[r] + v[half * 4 + r] * g[half * 4 + r] * scale;
+    out[i] = o;
+  }
+}
+
 static bool misaligned(const void* a) { return ((uintptr_t)a & 15) != 0; }
 
 }  // namespace rsa
@@ -590,7 +654,12 @@ extern "C" int rsa_rect_attention(const rsa_rect_attn_params* p, void* stream) {
   if (!p->qkv_hi || !p->bias_frag || !p->out_hi || (p->products == 3 && !p->qkv_lo)) return set_error(RSA_E_ARG, "rect_attention: null pointer");
   if (misaligned(p->qkv_hi) || misaligned(p->qkv_lo) || misaligned(p->bias_frag) || misaligned(p->out_hi) || misaligned(p->out_lo))
     return set_error(RSA_E_ALIGN, "rect_attention: pointers must be 16-byte aligned");
-  const int ntok = p->win_h * p->win_w;
+  const bool cross = p->kwin_h > 0 || p->kwin_w > 0;
+  if (cross) {
+    if (p->kwin_h < 1 || p->kwin_w < 1 || p->kpad_h < 0 || p->kpad_w < 0) return set_error(RSA_E_ARG, "rect_attention: bad key window");
+    if (p->shift_h != 0 || p->Hp != p->H || p->Wp != p->W) return set_error(RSA_E_UNSUPPORTED, "rect_attention: the cross-window mode takes no shift and no padding");
+  }
+  const int ntok = cross ? p->kwin_h * p->kwin_w : p->win_h * p->win_w;
   const int tiles = (ntok + 31) / 32;
   const int T = tiles <= 1 ? 1 : tiles <= 2 ? 2 : tiles <= 4 ? 4 : 8;
   const int64_t blocks = (int64_t)p->batch * (p->Hp / p->win_h) * (p->Wp / p->win_w) * p->heads;
@@ -697,4 +766,16 @@ extern "C" int rsa_aim_combine(const rsa_aim_params* p, void* stream) {
   hipLaunchKernelGGL(aim_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)p->batch), dim3(256), 0, (hipStream_t)stream, *p);
   const hipError_t rc = hipGetLastError();
   return rc ? set_error(rc, "aim_combine: launch failed") : RSA_OK;
+}
+
+extern "C" int rsa_gated_add(const void* x_hi, const void* x_lo, int64_t plane_stride, int64_t batch_stride, int32_t batch, int32_t H, int32_t W,
+                             int32_t C, const float* gate, float scale, const float* base_f32, float* out_f32, void* stream) {
+  if (!x_hi || !gate || !base_f32 || !out_f32 || batch < 1 || batch > 65535 || H < 1 || W < 1 || C < 1 || C > 8 * 65535)
+    return set_error(RSA_E_ARG, "gated_add: bad argument");
+  if (misaligned(x_hi) || misaligned(x_lo) || misaligned(base_f32) || misaligned(out_f32)) return set_error(RSA_E_ALIGN, "gated_add: maps must be 16-byte aligned");
+  const int64_t HW = (int64_t)H * W;
+  hipLaunchKernelGGL(gated_add_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)((C + 7) / 8), (unsigned)batch), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16x8*)x_hi, (const bf16x8*)x_lo, plane_stride, batch_stride, HW, C, gate, scale, (const f32x4*)base_f32, (f32x4*)out_f32);
+  const hipError_t rc = hipGetLastError();
+  return rc ? set_error(rc, "gated_add: launch failed") : RSA_OK;
 }

@@ -150,6 +150,10 @@ class RectAttnParams(C.Structure):
         ('out_lo', C.c_void_p),
         ('out_plane_stride', C.c_int64),
         ('out_batch_stride', C.c_int64),
+        ('kwin_h', C.c_int32),
+        ('kwin_w', C.c_int32),
+        ('kpad_h', C.c_int32),
+        ('kpad_w', C.c_int32),
     ]
 
 
@@ -223,6 +227,7 @@ class ChannelGateParams(C.Structure):
         ('b2', C.c_void_p),
         ('workspace', C.c_void_p),
         ('gate', C.c_void_p),
+        ('relu', C.c_int32),
     ]
 
 
@@ -277,6 +282,7 @@ EXPORTS = (
     'rsa_channel_gate_workspace_bytes',
     'rsa_channel_gate',
     'rsa_aim_combine',
+    'rsa_gated_add',
     'rsa_image_u8_to_nchw',
     'rsa_nchw_to_image_u8',
 )
@@ -337,6 +343,9 @@ def load() -> C.CDLL:
     lib.rsa_plane_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
                                     C.c_void_p]  # fmt: skip
     lib.rsa_plane_stats.restype = C.c_int
+    lib.rsa_gated_add.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_float,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]  # fmt: skip
+    lib.rsa_gated_add.restype = C.c_int
     lib.rsa_image_u8_to_nchw.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     lib.rsa_image_u8_to_nchw.restype = C.c_int
     lib.rsa_nchw_to_image_u8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]

@@ -51,6 +51,10 @@ def main():
         'dat_x4_bf16_512': (
             synth.dat_state_dict(embed_dim=180, depth=(6,) * 6, num_heads=(6,) * 6, split_size=(8, 32), expansion_factor=4.0, upscale=4, img_size=64),
             (1, 3, 512, 512), torch.bfloat16, None, None),
+        # HAT x4 at its published size (embed 180, 6 groups x 6 blocks, 6 heads, window 16, overlap 0.5, mlp 2)
+        'hat_x4_bf16_512': (
+            synth.hat_state_dict(embed_dim=180, depths=(6,) * 6, num_heads=(6,) * 6, window=16, upscale=4, mlp_ratio=2.0),
+            (1, 3, 512, 512), torch.bfloat16, None, None),
     }  # fmt: skip
     for name, (sd, shape, dt, flop_px, bytes_px) in cases.items():
         if args.only and args.only not in name:
