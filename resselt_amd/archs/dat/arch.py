@@ -392,7 +392,7 @@ class DAT(EngineModule):
         def launch(fn_name, params):
             fn = getattr(lib, fn_name)
             plan.call(lambda: L.check(fn(C.byref(params), stream()), fn_name))
-            plan._n_launches = plan.n_launches() + 1
+            plan.count_launches(1)
 
         x_pl = plan.planes(n, (c + 7) // 8, H, Wd, with_lo)
         mean = W['mean']
@@ -461,7 +461,7 @@ class DAT(EngineModule):
             cpar.temperature = W[f'{b}.attn.temperature'].data_ptr()
             cpar.workspace, cpar.w_packed = ws_attn.data_ptr(), wdyn[heads].data_ptr()
             launch('rsa_channel_attention_weights', cpar)
-            plan._n_launches = plan.n_launches() + 1  # two kernels
+            plan.count_launches(1)  # two kernels
             for bi in range(n):  # attn @ v: the weights differ per image
                 wts = ops.ConvWeights(wdyn[heads][bi], zero_bias, heads * HEAD_PAD, heads * HEAD_PAD, hp, 1, products)
                 src = Planes(qkv_pl.hi[bi : bi + 1], None if qkv_pl.lo is None else qkv_pl.lo[bi : bi + 1])
@@ -492,7 +492,7 @@ class DAT(EngineModule):
             gp.w1, gp.b1, gp.w2, gp.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
             gp.workspace, gp.gate = ws_gate.data_ptr(), gate.data_ptr()
             launch('rsa_channel_gate', gp)
-            plan._n_launches = plan.n_launches() + 1  # two kernels
+            plan.count_launches(1)  # two kernels
 
         def aim_combine(a, heads, mode):
             w1, b1, w2, b2 = W[f'{a}.si']
@@ -513,7 +513,7 @@ class DAT(EngineModule):
                                             stats.data_ptr(), stream()), 'rsa_plane_stats')  # fmt: skip
 
             plan.call(run)
-            plan._n_launches = plan.n_launches() + 1
+            plan.count_launches(1)
 
         def resi_conv(name, src_planes, res, out_f32=None, out_planes=None):
             if self.resi == '1conv':

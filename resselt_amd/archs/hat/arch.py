@@ -279,7 +279,7 @@ class HAT(EngineModule):
         def launch(fn_name, params, kernels=1):
             fn = getattr(lib, fn_name)
             plan.call(lambda: L.check(fn(C.byref(params), stream()), fn_name))
-            plan._n_launches = plan.n_launches() + kernels
+            plan.count_launches(kernels)
 
         x_pl = plan.planes(n, (c + 7) // 8, H, Wd, with_lo)
         mean = W['mean']
@@ -344,7 +344,7 @@ class HAT(EngineModule):
                                           self.conv_scale, shortcut.data_ptr(), out_f32.data_ptr(), stream()), 'rsa_gated_add')  # fmt: skip
 
             plan.call(run)
-            plan._n_launches = plan.n_launches() + 1
+            plan.count_launches(1)
 
         def mlp(b, x1, x2, out_planes=None):
             layernorm(f'{b}.norm2', x1, out_planes=a_pl)

@@ -178,7 +178,7 @@ class SpanPlus(EngineModule):
                 L.check(lib.rsa_dysample(C.byref(dp), C.c_void_p(ops.current_stream_ptr(dev))), 'rsa_dysample')
 
             plan.call(run_dysample)
-            plan._n_launches = plan.n_launches() + 1
+            plan.count_launches(1)
 
         def get_output():
             return out_buf.pop('y')

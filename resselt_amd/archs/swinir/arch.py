@@ -327,7 +327,7 @@ class SwinIR(EngineModule):
                 lp.out_plane_stride, lp.out_batch_stride = out_planes.plane_stride, out_planes.batch_stride
             lp.out_f32 = None if out_f32 is None else out_f32.data_ptr()
             plan.call(lambda: L.check(lib.rsa_layernorm(C.byref(lp), C.c_void_p(ops.current_stream_ptr(dev))), 'rsa_layernorm'))
-            plan._n_launches = plan.n_launches() + 1
+            plan.count_launches(1)
 
         def attention(name, heads, shift):
             ap = L.WindowAttnParams()
@@ -338,7 +338,7 @@ class SwinIR(EngineModule):
             ap.out_hi, ap.out_lo = o_pl.hi_ptr(), o_pl.lo_ptr()
             ap.out_plane_stride, ap.out_batch_stride = o_pl.plane_stride, o_pl.batch_stride
             plan.call(lambda: L.check(lib.rsa_window_attention(C.byref(ap), C.c_void_p(ops.current_stream_ptr(dev))), 'rsa_window_attention'))
-            plan._n_launches = plan.n_launches() + 1
+            plan.count_launches(1)
 
         def resi_conv(name, src_planes, res, out_f32=None, out_planes=None):
             """1conv / 3conv tail (arch.py:562-574) + the residual add that follows it."""

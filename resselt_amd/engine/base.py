@@ -86,6 +86,10 @@ class Plan:
     def n_launches(self) -> int:
         return getattr(self, '_n_launches', 0)
 
+    def count_launches(self, k: int = 1) -> None:
+        """Book-keeping for kernels launched from ``call`` steps (the convolution list counts its own)."""
+        self._n_launches = self.n_launches() + k
+
     def conv_bytes(self) -> int:
         """Algorithmic HBM bytes of the convolution launches in THIS engine's layouts (see ``conv_algorithmic_bytes``)."""
         return getattr(self, '_conv_bytes', 0)
