@@ -30,6 +30,7 @@ from resselt_amd.utils import synth  # noqa: E402
 def main():
     from oracle.compact import compact_forward
     from oracle.dat import dat_forward
+    from oracle.hat import hat_forward
     from oracle.rrdbnet import rrdbnet_forward
     from oracle.span import span_forward, spanplus_forward
     from oracle.swinir import swinir_forward
@@ -42,8 +43,14 @@ def main():
         ('span_x4_fp16_b2_512', synth.span_state_dict(upscale=4), (2, 3, 512, 512), torch.float16, span_forward),
         ('C4_swinir_L_x4_bf16_256', synth.swinir_state_dict(embed_dim=240, depths=[6] * 9, num_heads=[8] * 9, upscale=4, upsampler='nearest+conv',
                                                           resi='3conv'), (1, 3, 256, 256), torch.bfloat16, swinir_forward),
+        ('C4_swinir_L_x4_fp32_256', synth.swinir_state_dict(embed_dim=240, depths=[6] * 9, num_heads=[8] * 9, upscale=4, upsampler='nearest+conv',
+                                                          resi='3conv'), (1, 3, 256, 256), torch.float32, swinir_forward),
         ('dat_x4_bf16_128', synth.dat_state_dict(embed_dim=180, depth=(6,) * 6, num_heads=(6,) * 6, split_size=(8, 32), expansion_factor=4.0,
                                                  upscale=4, img_size=64), (1, 3, 128, 128), torch.bfloat16, dat_forward),
+        ('dat_x4_fp32_128', synth.dat_state_dict(embed_dim=180, depth=(6,) * 6, num_heads=(6,) * 6, split_size=(8, 32), expansion_factor=4.0,
+                                                 upscale=4, img_size=64), (1, 3, 128, 128), torch.float32, dat_forward),
+        ('hat_x4_fp32_128', synth.hat_state_dict(embed_dim=180, depths=(6,) * 6, num_heads=(6,) * 6, window=16, upscale=4, mlp_ratio=2.0),
+         (1, 3, 128, 128), torch.float32, hat_forward),
         ('compact_x4_fp16_b2_512', synth.compact_state_dict(num_feat=64, num_conv=16, upscale=4), (2, 3, 512, 512), torch.float16, compact_forward),
     ]  # fmt: skip
     only = sys.argv[1] if len(sys.argv) > 1 else ''
