@@ -78,18 +78,23 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
   lo = __builtin_bit_cast(uint32_t, l);
 }
 
-// Geometry of one instantiation.  Output tile = 16 rows x 32 pixels.  A COMPUTE wave owns 8 pixel-tiles (4 rows x 2 halves
-// of 16 pixels) x CTW cout-tiles; one tap costs it 16 LDS fragment reads + 2*CTW weight fragment loads for 24*CTW MFMAs.
-// NCT >= 2: 8 compute waves = 2 cout groups (CTW = ceil(NCT/2) tiles each) x 4 row-groups;  NCT == 1: 4 compute waves.
+// Geometry of one instantiation.  Output tile = 16 rows x 32 pixels.  A COMPUTE wave owns NPT pixel-tiles (RPW rows x 2 halves of
+// 16 pixels) x CTW cout-tiles; one tap costs it 2*NPT LDS fragment reads + 2*CTW weight fragment loads for 3*NPT*CTW MFMAs.
+//   NCT == 3 : 8 compute waves = 8 row-groups of 2 rows, every wave owns ALL 3 cout tiles of 4 pixel-tiles (no padded cout slot:
+//              the 2-group layout below would run 4 slots for 3 tiles -- SPAN-family layers with 48 channels);
+//   NCT == 2, 4 : 8 compute waves = 2 cout groups (NCT/2 tiles each) x 4 row-groups of 4 rows (8 pixel-tiles);
+//   NCT == 1 : 4 compute waves = 4 row-groups.
 // One extra LOADER wave per workgroup streams the halo tiles into the double-buffered LDS image by LDS-DMA.
 template <int KS, int NCT>
 struct GeoLW {
-  static constexpr int WCT = (NCT >= 2) ? 2 : 1;       // compute-wave groups along cout
-  static constexpr int WPX = 4;                        // compute-wave groups along rows (4 rows each)
-  static constexpr int NCW = WCT * WPX;                // compute waves
-  static constexpr int CTW = (NCT + WCT - 1) / WCT;    // cout tiles per compute wave (1 or 2)
-  static constexpr int NTHR = (NCW + 1) * 64;          // + loader wave
-  static constexpr int TH = 4 * WPX;                   // 16 output rows
+  static constexpr int WCT = (NCT == 2 || NCT == 4) ? 2 : 1;  // compute-wave groups along cout
+  static constexpr int WPX = (NCT == 3) ? 8 : 4;              // compute-wave groups along rows
+  static constexpr int NCW = WCT * WPX;                        // compute waves
+  static constexpr int CTW = (NCT + WCT - 1) / WCT;            // cout tiles per compute wave (1, 2 or 3)
+  static constexpr int NTHR = (NCW + 1) * 64;                  // + loader wave
+  static constexpr int TH = 16;                                // output rows of a tile
+  static constexpr int RPW = TH / WPX;                         // rows per compute wave (4 or 2)
+  static constexpr int NPT = 2 * RPW;                          // pixel tiles per compute wave (8 or 4)
   static constexpr int TW = 32;
   static constexpr int HALO = KS / 2;
   static constexpr int IH = TH + 2 * HALO;
@@ -100,16 +105,17 @@ struct GeoLW {
 
 // Epilogue of one finished tile.  Every address is  (uniform 64-bit base) + (32-bit per-lane byte offset):
 //   lane (li, lg) of wave (wct, wpx) owns, for pixel-tile pt and cout-tile c, the 4 consecutive channels
-//   c0 = 16*(slab*NCT + CTW*wct + c) + 4*lg .. +3  of pixel (y0 + 4*wpx + (pt>>1), x0 + 16*(pt&1) + li).
+//   c0 = 16*(slab*NCT + CTW*wct + c) + 4*lg .. +3  of pixel (y0 + RPW*wpx + (pt>>1), x0 + 16*(pt&1) + li),  RPW = NPT/2.
 // OUTK = 0: split planes and/or f32 residual map (with activation / residual epilogues)
 // OUTK = 1: final plain NCHW tensor (optional activation, depth-to-space and affine), any dtype
-template <int NCT, int CTW, int OUTK, int AC>
-__device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f32x4 (&acc)[8][CTW], int n, int y0, int x0, int slab, int wct,
+template <int NCT, int CTW, int NPT, int OUTK, int AC>
+__device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f32x4 (&acc)[NPT][CTW], int n, int y0, int x0, int slab, int wct,
                                               int wpx, int li, int lg) {
+  constexpr int RPW = NPT / 2;
 #ifdef RSA_ABL_NOEPI
   if (p.H > 0) {  // timing-only build: no epilogue, but every accumulator stays live (no dead-code elimination of the MFMAs)
 #pragma unroll
-    for (int pt = 0; pt < 8; ++pt)
+    for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
       for (int ct = 0; ct < CTW; ++ct) asm volatile("" ::"v"(acc[pt][ct]));
     return;
@@ -129,10 +135,10 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
   // per-lane pixel offset / validity of pixel-tile pt, recomputed at every use from ONE lane register and uniform terms: holding
   // them in arrays (and the 64-bit addresses the compiler derived from them) cost the 2-cout-tile epilogue ~40 scratch reloads per
   // tile, each of which had to wait (vmcnt, in order) for the stores issued before it
-  const uint32_t lbase = (uint32_t)(wpx * 4 * p.W + li);
+  const uint32_t lbase = (uint32_t)(wpx * RPW * p.W + li);
   const bool xv0 = x0 + li < p.W, xv1 = x0 + 16 + li < p.W;
   auto lpix_of = [&](int pt) -> uint32_t { return lbase + (uint32_t)((pt >> 1) * p.W + (pt & 1) * 16); };
-  auto pvalid_of = [&](int pt) -> bool { return (y0 + wpx * 4 + (pt >> 1) < p.H) && ((pt & 1) ? xv1 : xv0); };
+  auto pvalid_of = [&](int pt) -> bool { return (y0 + wpx * RPW + (pt >> 1) < p.H) && ((pt & 1) ? xv1 : xv0); };
 
   // vmcnt retires IN ORDER and counts stores: a load issued after a store cannot be waited for before that store's write is
   // acknowledged.  So every load of the epilogue is issued ahead of the stores it would otherwise queue behind: bias / slope
@@ -193,7 +199,7 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
     // bytes per plane and instruction instead of two half-filled 256-byte runs (the 8-byte form was store-issue bound:
     // profiles/r01_l_ab_epilogue.txt)
 #pragma unroll
-    for (int pp = 0; pp < 4; ++pp) {
+    for (int pp = 0; pp < RPW; ++pp) {
       float v[2][4];
       bool ok[2];
       f32x4 cr1[2], cr2[2];
@@ -203,7 +209,7 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
           cr1[e] = nr1[e];
           cr2[e] = nr2[e];
         }
-        if (pp + 1 < 4)
+        if (pp + 1 < RPW)
           fetch_res(ct, pp + 1);
         else if (ct + 1 < CTW)
           fetch_res(ct + 1, 0);
@@ -282,7 +288,7 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
           const int oc_total = p.cout / (ps * ps);
           const int64_t oW = (int64_t)p.W * ps;
           const int64_t oHW = (int64_t)p.H * ps * oW;
-          const int y = y0 + wpx * 4 + (pt >> 1), x = x0 + (pt & 1) * 16 + li;
+          const int y = y0 + wpx * RPW + (pt >> 1), x = x0 + (pt & 1) * 16 + li;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int c = c0 + r;
@@ -319,21 +325,21 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
   }
 }
 
-template <int NCT, int CTW, int OUTK>
-__device__ __forceinline__ void epilogue(const rsa_conv_params& p, const f32x4 (&acc)[8][CTW], int n, int y0, int x0, int slab, int wct, int wpx,
+template <int NCT, int CTW, int NPT, int OUTK>
+__device__ __forceinline__ void epilogue(const rsa_conv_params& p, const f32x4 (&acc)[NPT][CTW], int n, int y0, int x0, int slab, int wct, int wpx,
                                          int li, int lg) {
   switch (act_class(p.act)) {  // wave-uniform: one compact code path is fetched per tile
     case AC_MISH:
-      return epilogue_impl<NCT, CTW, OUTK, AC_MISH>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
+      return epilogue_impl<NCT, CTW, NPT, OUTK, AC_MISH>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
     case AC_SILU:
-      return epilogue_impl<NCT, CTW, OUTK, AC_SILU>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
+      return epilogue_impl<NCT, CTW, NPT, OUTK, AC_SILU>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
     case AC_GELU:
-      return epilogue_impl<NCT, CTW, OUTK, AC_GELU>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
+      return epilogue_impl<NCT, CTW, NPT, OUTK, AC_GELU>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
     case AC_GATE:
-      if (OUTK == 0) return epilogue_impl<NCT, CTW, OUTK, AC_GATE>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
+      if (OUTK == 0) return epilogue_impl<NCT, CTW, NPT, OUTK, AC_GATE>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
       return;
     default:
-      return epilogue_impl<NCT, CTW, OUTK, AC_LINEAR>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
+      return epilogue_impl<NCT, CTW, NPT, OUTK, AC_LINEAR>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
   }
 }
 

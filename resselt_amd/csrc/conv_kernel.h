@@ -6,7 +6,8 @@
 // (kernel size, products, upsample) family so that they compile in parallel) and dispatched from conv_mfma.hip.
 //
 // Mapping (one workgroup = 8 compute waves + 1 loader wave, one workgroup per CU, persistent over tiles):
-//   output tile   : 16 rows x 32 pixels; compute wave = 4 rows x 2 halves of 16 pixels = 8 pixel-tiles x CTW cout-tiles of 16
+//   output tile   : 16 rows x 32 pixels; compute wave = RPW rows x 2 halves of 16 pixels = NPT pixel-tiles x CTW cout-tiles of 16
+//                   (8 x 1-2 for 1, 2 or 4 cout tiles per slab; 4 x 3 for 3: see GeoLW in conv_common.h)
 //   MFMA          : v_mfma_f32_16x16x32_bf16,  D[cout 16][pixel 16] += A[cout][k 32] * B[k][pixel]
 //                   A = weights (lane l: cout l&15, k-group l>>4), pre-packed in fragment order and streamed by each wave
 //                       straight from L2 into VGPRs one tap ahead (waves own disjoint cout tiles or rows, so nothing is
@@ -37,7 +38,7 @@ template <int KS, int NCT, int PROD, int UP, int OUTK>
 __global__ __launch_bounds__((GeoLW<KS, NCT>::NTHR), (GeoLW<KS, NCT>::NCW == 8 ? 3 : 2)) void conv_kernel(const rsa_conv_params p) {
   using G = GeoLW<KS, NCT>;
   constexpr int TH = G::TH, TW = G::TW, HALO = G::HALO, IH = G::IH, IW = G::IW, PS = G::PS;
-  constexpr int WPX = G::WPX, CTW = G::CTW, NCW = G::NCW;
+  constexpr int WPX = G::WPX, CTW = G::CTW, NCW = G::NCW, NPT = G::NPT, RPW = G::RPW;
   constexpr int ACT_UNITS = NPL * PS;
   constexpr int NHL = (PROD == 3) ? 2 : 1;
   constexpr int DMA_IT = (ACT_UNITS + 63) / 64;  // LDS-DMA instructions (1 KiB each) per precision per chunk
@@ -144,7 +145,7 @@ __global__ __launch_bounds__((GeoLW<KS, NCT>::NTHR), (GeoLW<KS, NCT>::NCW == 8 ?
   const int li = lane & 15;
   const int lg = lane >> 4;
 
-  // ---- weights: every wave streams ITS OWN A fragments (cout tiles 2*wct, 2*wct+1 of this slab) straight from the
+  // ---- weights: every wave streams ITS OWN A fragments (cout tiles CTW*wct .. CTW*wct + CTW-1 of this slab) straight from the
   //      L2-resident packed blob into VGPRs, one tap ahead.  No LDS, no barrier: waves never share weight registers. ----
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.w_packed, 0, (uint32_t)((int64_t)nsteps * ct_total * NHL * 64 * 16), 0x00020000);
@@ -171,14 +172,14 @@ __global__ __launch_bounds__((GeoLW<KS, NCT>::NTHR), (GeoLW<KS, NCT>::NCW == 8 ?
       }
   };
 
-  f32x4 acc[8][CTW];
+  f32x4 acc[NPT][CTW];
 #pragma unroll
-  for (int pt = 0; pt < 8; ++pt)
+  for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
     for (int ct = 0; ct < CTW; ++ct) acc[pt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // B-fragment unit of (pixel-tile 0, tap 0,0) for this lane
-  const int bunit0 = lg * PS + (wpx * 4) * IW + li;
+  const int bunit0 = lg * PS + (wpx * RPW) * IW + li;
 
   load_w(0);
   int k = 0;
@@ -196,8 +197,8 @@ __global__ __launch_bounds__((GeoLW<KS, NCT>::NTHR), (GeoLW<KS, NCT>::NCW == 8 ?
       // software pipeline over the (tap, pixel-tile group) steps of the chunk: the B fragments of step i+LDS_DEPTH are
       // read from LDS while step i multiplies.  A step covers GP pixel tiles with GP*CTW == 2 accumulator tiles, and its
       // MFMAs are issued product-major, so two dependent MFMAs on one accumulator are never back to back.
-      constexpr int GP = 2 / CTW;          // pixel tiles per step (1 when the wave owns 2 cout tiles, else 2)
-      constexpr int SPT = 8 / GP;          // steps per tap
+      constexpr int GP = (CTW >= 2) ? 1 : 2;  // pixel tiles per step (1 when the wave owns 2-3 cout tiles, else 2)
+      constexpr int SPT = NPT / GP;          // steps per tap
       constexpr int NSTEP = T * SPT;
       constexpr int LDS_DEPTH = 2;
       bf16x8 rh[LDS_DEPTH + 1][GP], rl[LDS_DEPTH + 1][GP];
@@ -270,10 +271,10 @@ __global__ __launch_bounds__((GeoLW<KS, NCT>::NTHR), (GeoLW<KS, NCT>::NCW == 8 ?
       const int tr = tile - n * tiles_img;
       const int ty = tr / tiles_x;
       const int tx = tr - ty * tiles_x;
-      epilogue<NCT, CTW, OUTK>(p, acc, n, ty * TH, tx * TW, slab, wct, wpx, li, lg);
+      epilogue<NCT, CTW, NPT, OUTK>(p, acc, n, ty * TH, tx * TW, slab, wct, wpx, li, lg);
     }
 #pragma unroll
-    for (int pt = 0; pt < 8; ++pt)
+    for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
       for (int ct = 0; ct < CTW; ++ct) acc[pt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
     set_slab(slab + 1 < nslabs ? slab + 1 : 0);
