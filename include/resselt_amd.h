@@ -166,7 +166,8 @@ typedef struct rsa_dysample_params {
   const float* x_f32;    /* features, f32 NCHW4c [N][C/4][H][W][4] */
   const float* offscope; /* f32 NCHW4c [N][2*oc/4][H][W][4] */
   const float* init_pos; /* [oc] (registered buffer of the reference module, dysample.py:43-45) */
-  const float* end_w;    /* [out_ch][C] */
+  const float* end_w;    /* [out_ch][C]; NULL = x_f32 is PRE-PROJECTED: C == 4*groups, channel 4g+o = sum over the channels c of group g of
+                            W_end[o][c] * x[c] (the 1x1 end conv applied per group at low resolution; sampling is linear), out_ch <= 4 */
   const float* end_b;    /* [out_ch] or NULL */
   void* out_nchw;        /* [N][out_ch][H*scale][W*scale] */
   int32_t out_dtype;     /* enum rsa_dtype */

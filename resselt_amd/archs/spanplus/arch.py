@@ -91,6 +91,15 @@ class SpanPlus(EngineModule):
             w = torch.cat([sd['upsampler.offset.weight'], sd['upsampler.scope.weight']], 0)
             b = torch.cat([sd['upsampler.offset.bias'], torch.zeros_like(sd['upsampler.offset.bias'])], 0)
             W['upsampler.offscope'] = ops.ConvWeights.from_oihw(w, b, products, device=device)
+            end_w = sd['upsampler.end_conv.weight'].reshape(self.out_ch, self.fc)
+            if self.out_ch <= 4:
+                # bilinear sampling is linear: the 1x1 end conv is applied per channel group BEFORE the sampling, at low resolution
+                # (rsa_dysample's pre-projected mode): z[4g + o] = sum over the channels c of group g of W_end[o][c] * x[c]
+                cpg = self.fc // _GROUPS
+                wz = torch.zeros((4 * _GROUPS, self.fc), dtype=torch.float32, device=device)
+                for g in range(_GROUPS):
+                    wz[4 * g : 4 * g + self.out_ch, g * cpg : (g + 1) * cpg] = end_w[:, g * cpg : (g + 1) * cpg]
+                W['upsampler.zproj'] = ops.ConvWeights.from_oihw(wz[:, :, None, None], None, products, device=device)
             W['dys'] = dict(
                 init_pos=sd['upsampler.init_pos'].reshape(-1).contiguous(),
                 end_w=sd['upsampler.end_conv.weight'].reshape(self.out_ch, self.fc).contiguous(),
@@ -117,7 +126,8 @@ class SpanPlus(EngineModule):
         with_lo = products == 3
         x_pl = plan.planes(n, (c + 7) // 8, h, w, with_lo)
         chain = SpabChain(plan, W, n, h, w, fc, L.ACT_MISH, with_lo)
-        need_f32_feat = self.upsampler_kind == 'dys'
+        preproj = self.upsampler_kind == 'dys' and 'upsampler.zproj' in W
+        need_f32_feat = self.upsampler_kind == 'dys' and not preproj
 
         def set_input(x):
             ops.nchw_to_planes(x, x_pl)
@@ -164,9 +174,13 @@ class SpanPlus(EngineModule):
             plan.flush()
             d = W['dys']
             dp = L.DySampleParams()
-            dp.batch, dp.H, dp.W, dp.C, dp.groups, dp.scale, dp.out_ch = n, h, w, fc, _GROUPS, s, self.out_ch
-            dp.x_f32, dp.offscope = feat_f32.data_ptr(), offscope.data_ptr()
-            dp.init_pos, dp.end_w, dp.end_b = d['init_pos'].data_ptr(), d['end_w'].data_ptr(), d['end_b'].data_ptr()
+            if preproj:
+                z = plan.f32map(n, 4 * _GROUPS, h, w)
+                plan.conv(ops.conv_params(W['upsampler.zproj'], feat, h, w, out_f32=z))
+                plan.flush()
+            dp.batch, dp.H, dp.W, dp.C, dp.groups, dp.scale, dp.out_ch = n, h, w, (4 * _GROUPS if preproj else fc), _GROUPS, s, self.out_ch
+            dp.x_f32, dp.offscope = (z if preproj else feat_f32).data_ptr(), offscope.data_ptr()
+            dp.init_pos, dp.end_w, dp.end_b = d['init_pos'].data_ptr(), (None if preproj else d['end_w'].data_ptr()), d['end_b'].data_ptr()
             dp.out_dtype = ops.rsa_dtype(dtype)
             lib = L.load()
             dev = plan.device

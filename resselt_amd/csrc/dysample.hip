@@ -8,6 +8,8 @@
 // feature map (NCHW4c, 16-byte loads) and applies the 1x1 end convolution in registers.
 // The two 1x1 convs (offset with bias, scope without) are run by the conv engine as one k1 convolution whose
 // f32 NCHW4c output holds offset channels [0, oc) and scope channels [oc, 2*oc), oc = 2*groups*scale^2.
+// Pre-projected mode (end_w == NULL): the 1x1 end convolution is applied per channel group BEFORE the sampling, at low resolution
+// (bilinear sampling is linear), so the gather touches 4 floats per group instead of C/groups channels.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -62,6 +64,16 @@ __global__ __launch_bounds__(256) void dysample_kernel(const rsa_dysample_params
       const int x1 = min(x0 + 1, p.W - 1), y1 = min(y0 + 1, p.H - 1);
       const float w00 = (1.f - ax) * (1.f - ay), w01 = ax * (1.f - ay), w10 = (1.f - ax) * ay, w11 = ax * ay;
       const int64_t p00 = (int64_t)y0 * p.W + x0, p01 = (int64_t)y0 * p.W + x1, p10 = (int64_t)y1 * p.W + x0, p11 = (int64_t)y1 * p.W + x1;
+      if (p.end_w == nullptr) {
+        // pre-projected input: bilinear sampling is linear, so end_conv(sample_g(x)) = sample_g(end_conv restricted to group g);
+        // x_f32 then holds z[g][0..3] = sum_{c in g} W_end[o][c] x_c (one f32x4 per group), a 1x1 convolution run at LOW resolution
+        const f32x4* plane = (const f32x4*)(xb + (int64_t)g * HW * 4);
+        const f32x4 v00 = plane[p00], v01 = plane[p01], v10 = plane[p10], v11 = plane[p11];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < p.out_ch) out[r] += v00[r] * w00 + v01[r] * w01 + v10[r] * w10 + v11[r] * w11;
+        continue;
+      }
       for (int q = 0; q < cpg4; ++q) {
         const f32x4* plane = (const f32x4*)(xb + (int64_t)(g * cpg4 + q) * HW * 4);
         const f32x4 v00 = plane[p00], v01 = plane[p01], v10 = plane[p10], v11 = plane[p11];
@@ -99,7 +111,8 @@ extern "C" int rsa_dysample(const rsa_dysample_params* p, void* stream) {
   if (p->C % (4 * p->groups) != 0) return set_error(RSA_E_UNSUPPORTED, "dysample: C must be a multiple of 4*groups");
   if ((2 * p->groups * p->scale * p->scale) % 2 != 0) return set_error(RSA_E_UNSUPPORTED, "dysample: bad offset channel count");
   if (p->out_ch < 1 || p->out_ch > DYS_MAX_OUT) return set_error(RSA_E_UNSUPPORTED, "dysample: out_ch must be 1..8");
-  if (!p->x_f32 || !p->offscope || !p->init_pos || !p->end_w || !p->out_nchw) return set_error(RSA_E_ARG, "dysample: null pointer");
+  if (!p->x_f32 || !p->offscope || !p->init_pos || !p->out_nchw) return set_error(RSA_E_ARG, "dysample: null pointer");
+  if (!p->end_w && (p->C != 4 * p->groups || p->out_ch > 4)) return set_error(RSA_E_ARG, "dysample: pre-projected input needs C == 4*groups and out_ch <= 4");
   if (p->out_dtype < RSA_F32 || p->out_dtype > RSA_BF16) return set_error(RSA_E_ARG, "dysample: bad out_dtype");
   if (((uintptr_t)p->x_f32 | (uintptr_t)p->offscope) & 15) return set_error(RSA_E_ALIGN, "dysample: maps must be 16-byte aligned");
   const int64_t total = (int64_t)p->batch * p->H * p->scale * p->W * p->scale;
