@@ -20,6 +20,9 @@ if which == 'dat':
 elif which == 'swinir':
     sd = synth.swinir_state_dict(embed_dim=240, depths=[6] * 9, num_heads=[8] * 9, upscale=4, upsampler='nearest+conv', resi='3conv')
     shape, dt = (1, 3, 1024, 1024), torch.bfloat16
+elif which == 'hat':
+    sd = synth.hat_state_dict(embed_dim=180, depths=(6,) * 6, num_heads=(6,) * 6, window=16, upscale=4, mlp_ratio=2.0)
+    shape, dt = (1, 3, 512, 512), torch.bfloat16
 elif which == 'spanplus':
     sd = synth.spanplus_state_dict(upscale=4, upsampler='ps')
     shape, dt = (8, 3, 512, 512), torch.float16
