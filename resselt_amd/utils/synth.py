@@ -474,3 +474,39 @@ def hat_state_dict(in_chans=3, embed_dim=60, depths=(2, 2), num_heads=(6, 6), wi
             _conv(sd, f'upsample.{2 * u}', 4 * num_feat, num_feat, 3, seed)
     _conv(sd, 'conv_last', in_chans, num_feat, 3, seed)
     return sd
+
+
+def rtmosr_state_dict(scale=2, dim=32, ffn_expansion=2.0, n_blocks=2, unshuffle_mod=False, dccm=True, se=True, seed=0):
+    """Keys of the reference RTMoSR module (archs/rtmosr/arch.py:340-387)."""
+    sd: OrderedDict = OrderedDict()
+    unshuffle = 0
+    s_int = scale
+    if scale < 4 and unshuffle_mod:
+        unshuffle = 4 // scale
+        s_int = 4
+    hidden = int(ffn_expansion * dim)
+    if unshuffle:
+        _repconv(sd, 'to_feat.1', dim, 3 * unshuffle * unshuffle, seed)
+    else:
+        _repconv(sd, 'to_feat', dim, 3, seed)
+    for i in range(n_blocks):
+        b = f'body.{i}'
+        sd[f'{b}.norm.scale'] = 1.0 + synth_tensor(f'{b}.norm.scale', (dim,), 16, seed)
+        sd[f'{b}.norm.offset'] = synth_tensor(f'{b}.norm.offset', (dim,), 16, seed)
+        _repconv(sd, f'{b}.fc1', 2 * hidden, dim, seed)
+        _repconv(sd, f'{b}.conv.0.poll.1', 4 * dim, dim, seed)
+        o = f'{b}.conv.1'
+        for k in (1, 2, 3, 4):
+            sd[f'{o}.alpha{k}'] = 1.0 + synth_tensor(f'{o}.alpha{k}', (1, 4 * dim, 1, 1), 16, seed)
+        for name, ks in (('conv1x1', 1), ('conv3x3', 3), ('conv5x5', 5), ('conv5x5_reparam', 5)):
+            sd[f'{o}.{name}.weight'] = synth_tensor(f'{o}.{name}.weight', (4 * dim, 1, ks, ks), ks * ks, seed)
+            sd[f'{o}.{name}.bias'] = synth_tensor(f'{o}.{name}.bias', (4 * dim,), ks * ks, seed)
+        if se:
+            _conv(sd, f'{b}.conv.2.squeezing.0', 2 * dim, 4 * dim, 1, seed)
+            _conv(sd, f'{b}.conv.2.squeezing.2', 4 * dim, 2 * dim, 1, seed)
+        if dccm:
+            _repconv(sd, f'{b}.fc2', dim, hidden, seed)
+        else:
+            _conv(sd, f'{b}.fc2', dim, hidden, 1, seed)
+    _repconv(sd, 'to_img.0', 3 * s_int * s_int, dim, seed)
+    return sd

@@ -29,7 +29,7 @@ def synth_state_dict(meta):
         if k in kw:
             kw[k] = tuple(kw[k])
     fn = {'esrgan': synth.rrdbnet_state_dict, 'spanplus': synth.spanplus_state_dict, 'span': synth.span_state_dict,
-          'swinir': getattr(synth, 'swinir_state_dict', None), 'compact': synth.compact_state_dict, 'dat': getattr(synth, 'dat_state_dict', None), 'spanpp': getattr(synth, 'spanpp_state_dict', None), 'hat': getattr(synth, 'hat_state_dict', None)}[meta['arch']]  # fmt: skip
+          'swinir': getattr(synth, 'swinir_state_dict', None), 'compact': synth.compact_state_dict, 'dat': getattr(synth, 'dat_state_dict', None), 'spanpp': getattr(synth, 'spanpp_state_dict', None), 'hat': getattr(synth, 'hat_state_dict', None), 'rtmosr': getattr(synth, 'rtmosr_state_dict', None)}[meta['arch']]  # fmt: skip
     return fn(seed=meta['seed'], **kw)
 
 
@@ -58,6 +58,10 @@ def oracle_forward(meta, sd, x):
         from oracle.spanpp import spanpp_forward
 
         return spanpp_forward(sd, x, meta.get('scale'))
+    if meta['arch'] == 'rtmosr':
+        from oracle.rtmosr import rtmosr_forward
+
+        return rtmosr_forward(sd, x)
     if meta['arch'] == 'hat':
         from oracle.hat import hat_forward
 

@@ -231,6 +231,22 @@ def hat_cases():
         save(name, dict(arch='hat', synth=kw, seed=seed, metadata=meta_of(model), mode='eval'), x=x, y=y)
 
 
+def rtmosr_cases():
+    """RTMoSR end to end, eval mode (every RepConv / OmniShift re-parameterised; the train-mode branches are the same function)."""
+    cases = [
+        ('rtmosr_x2_d32_b2_13x17', dict(), (1, 3, 13, 17), 111),
+        ('rtmosr_x4_d48_b2_nose_b2_20x28', dict(scale=4, dim=48, se=False), (2, 3, 20, 28), 112),
+        ('rtmosr_x2_unshuffle_d32_ffn15_nodccm_21x30', dict(scale=2, dim=32, ffn_expansion=1.5, n_blocks=1, unshuffle_mod=True, dccm=False), (1, 3, 21, 30), 113),
+        # (scale 1 with unshuffle 4 cannot load in the reference: its loader reads the unshuffle factor as the scale, rtmosr/__init__.py:178-180)
+    ]
+    for name, kw, shape, seed in cases:
+        sd = synth.rtmosr_state_dict(seed=seed, **kw)
+        model = resselt.load_from_state_dict(dict(sd)).eval()
+        x = synth.synth_input(shape, seed)
+        y = model(x)
+        save(name, dict(arch='rtmosr', synth=kw, seed=seed, metadata=meta_of(model), mode='eval'), x=x, y=y)
+
+
 def registry_cases():
     """Detection order facts: which reference architecture claims each synthetic checkpoint."""
     claims = {}
@@ -243,6 +259,7 @@ def registry_cases():
         ('swinir', synth.swinir_state_dict()),
         ('dat', synth.dat_state_dict()),
         ('hat', synth.hat_state_dict()),
+        ('rtmosr', synth.rtmosr_state_dict()),
         ('spanpp', synth.spanpp_state_dict(feature_channels=16, implicit_dim=32, latent_layers=1)),
     ):
         for arch in resselt.archs.internal_registry.store.values():
@@ -253,7 +270,7 @@ def registry_cases():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['esrgan', 'blocks', 'span', 'compact', 'registry', 'swinir', 'dat', 'spanpp', 'hat']
+    which = sys.argv[1:] or ['esrgan', 'blocks', 'span', 'compact', 'registry', 'swinir', 'dat', 'spanpp', 'hat', 'rtmosr']
     if 'esrgan' in which:
         esrgan_cases()
     if 'blocks' in which:
@@ -268,6 +285,8 @@ if __name__ == '__main__':
         spanpp_cases()
     if 'hat' in which:
         hat_cases()
+    if 'rtmosr' in which:
+        rtmosr_cases()
     if 'registry' in which:
         registry_cases()
     if 'swinir' in which:
