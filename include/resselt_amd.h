@@ -115,6 +115,10 @@ typedef struct rsa_conv_params {
   const float* act_vec;     /* RSA_ACT_PRELU: negative slopes, f32[round_up(cout,16)], 16-byte aligned */
   const void* out_base;     /* optional with out_nchw: plain [N][cout/r^2][H][W] tensor of dtype out_dtype whose pixel (y,x) is
                                ADDED to all r x r output pixels it covers (nearest-upsampled base image, compact/arch.py:61-64) */
+  int32_t out_base_div;     /* 0: the base image is H x W as described above.  > 0: the base image is out_base_h x out_base_w and output pixel
+                               (Y, X) receives base pixel (min(Y / div, h-1), min(X / div, w-1)) -- F.interpolate(x, scale_factor=div) of the
+                               UNPADDED input under a padded / unshuffled convolution grid (rtmosr/arch.py:383-387) */
+  int32_t out_base_h, out_base_w;
 } rsa_conv_params;
 
 /* Launch `n` fused convolutions in order on `stream` (one host call per forward pass). */
@@ -312,6 +316,9 @@ typedef struct rsa_dwconv_params {
   int64_t out_batch_stride;
 } rsa_dwconv_params;
 int rsa_dwconv3x3(const rsa_dwconv_params* p, void* stream);
+/* Depthwise 5x5, zero padding 2, weight [planes*8][25]: OmniShift of RTMoSR re-parameterised to one kernel (archs/rtmosr/arch.py:253-289).
+ * act must be RSA_ACT_NONE and stats NULL; the optional multiplier map is supported. */
+int rsa_dwconv5x5(const rsa_dwconv_params* p, void* stream);
 
 /* Per-pixel LayerNorm statistics over channels [0, C) of a plane range: stats[b][pixel] = (mean, 1/sqrt(var + eps)). */
 int rsa_plane_stats(const void* in_hi, const void* in_lo, int64_t plane_stride, int64_t batch_stride, int32_t batch, int32_t H, int32_t W,
@@ -334,7 +341,8 @@ typedef struct rsa_channel_gate_params {
   const float* b2;           /* [C] */
   float* workspace;
   float* gate;               /* [batch][C] */
-  int32_t relu;              /* hidden activation: 0 = GELU (DAT), 1 = ReLU (the RCAN-style channel attention of HAT's CAB, archs/hat/arch.py:28-35) */
+  int32_t relu;              /* 0 = GELU hidden, sigmoid gate (DAT); 1 = ReLU, sigmoid (the RCAN-style channel attention of HAT's CAB,
+                                archs/hat/arch.py:28-35); 2 = ReLU, Hardsigmoid (RTMoSR's CSELayer, archs/rtmosr/arch.py:7-22) */
 } rsa_channel_gate_params;
 int64_t rsa_channel_gate_workspace_bytes(int32_t batch, int32_t H, int32_t W, int32_t planes);
 int rsa_channel_gate(const rsa_channel_gate_params* p, void* stream);
@@ -372,6 +380,45 @@ int rsa_aim_combine(const rsa_aim_params* p, void* stream);
  * HAT's `shortcut + conv_x * conv_scale` with the CAB's channel attention as the gate (reference archs/hat/arch.py:37-39, 345). */
 int rsa_gated_add(const void* x_hi, const void* x_lo, int64_t plane_stride, int64_t batch_stride, int32_t batch, int32_t H, int32_t W, int32_t C,
                   const float* gate, float scale, const float* base_f32, float* out_f32, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------- RTMoSR ops
+ * (reference archs/rtmosr/arch.py; every RepConv / OmniShift is re-parameterised to one kernel by the host) */
+
+/* RMSNorm over channels (arch.py:32-37): out = scale[c] * x / (||x||_2 / sqrt(C) + eps) + offset[c];  f32 map in, split planes out. */
+int rsa_rmsnorm(const float* x_f32, int32_t batch, int32_t H, int32_t W, int32_t C, float eps, const float* scale, const float* offset, void* out_hi,
+                void* out_lo, int64_t out_plane_stride, int64_t out_batch_stride, void* stream);
+
+/* ParPixelUnshuffle's two reads of its input (arch.py:292-299), `planes` planes of H x W (both even):
+ *   unshuffled_f32: PixelUnshuffle(2) as an f32 map [N][planes*8][H/2][W/2][4] (f32 group c holds the 2x2 block of channel c) -- the
+ *                   residual operand of the RepConv that follows;  pool: MaxPool2d(2) as split planes [N][planes][H/2][W/2][8]. */
+int rsa_unshuffle_pool(const void* in_hi, const void* in_lo, int64_t in_plane_stride, int64_t in_batch_stride, int32_t batch, int32_t H, int32_t W,
+                       int32_t planes, float* unshuffled_f32, void* pool_hi, void* pool_lo, int64_t pool_plane_stride, int64_t pool_batch_stride,
+                       void* stream);
+
+/* The gate of GatedCNNBlock.forward (arch.py:334-336):  out = mish(g) * cat(i, PixelShuffle(2)(c * gate)).
+ * g = planes [0, g_planes) and i = planes [g_planes, g_planes + i_planes) of the fc1 output `f` (H x W); c = (g_planes - i_planes)*4
+ * planes at H/2 x W/2 (the OmniShift output); gate = the SE layer's per-channel factors of c, or NULL. */
+typedef struct rsa_gated_shuffle_params {
+  int32_t batch;
+  int32_t H, W;              /* both even */
+  int32_t g_planes;          /* planes of g = planes of the output */
+  int32_t i_planes;          /* planes of i */
+  const void* f_hi;
+  const void* f_lo;          /* may be NULL */
+  int64_t f_plane_stride;
+  int64_t f_batch_stride;
+  const void* c_hi;
+  const void* c_lo;
+  int64_t c_plane_stride;
+  int64_t c_batch_stride;
+  const float* gate;         /* [batch][gate_stride] or NULL */
+  int64_t gate_stride;
+  void* out_hi;
+  void* out_lo;
+  int64_t out_plane_stride;
+  int64_t out_batch_stride;
+} rsa_gated_shuffle_params;
+int rsa_gated_shuffle_mul(const rsa_gated_shuffle_params* p, void* stream);
 
 /* 8-bit images either side of the path (the reference leaves both steps to its callers):
  *   rsa_image_u8_to_nchw   uint8 [N][H][W][C] (interleaved, as image decoders deliver it) -> float [N][C][H][W], v / 255

@@ -300,7 +300,13 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
             float o = v[e][r] * p.out_scale;
             if (p.out_shift != nullptr) o += p.out_shift[oc];
             if (p.out_base != nullptr) {  // nearest-upsampled base image: the low-resolution pixel this output pixel sits in
-              const int64_t bi = (((int64_t)n * oc_total + oc) * p.H + y) * p.W + x;
+              int64_t bi = (((int64_t)n * oc_total + oc) * p.H + y) * p.W + x;
+              if (p.out_base_div > 0) {
+                int by = (y * ps + ii) / p.out_base_div, bx = (x * ps + jj) / p.out_base_div;
+                by = by < p.out_base_h ? by : p.out_base_h - 1;
+                bx = bx < p.out_base_w ? bx : p.out_base_w - 1;
+                bi = (((int64_t)n * oc_total + oc) * p.out_base_h + by) * p.out_base_w + bx;
+              }
               if (p.out_dtype == RSA_F32)
                 o += ((const float*)p.out_base)[bi];
               else if (p.out_dtype == RSA_F16)

@@ -402,8 +402,9 @@ __global__ __launch_bounds__(1024) void channel_attn_finish_kernel(const rsa_cha
 
 // ------------------------------------------------------------------------------------------------ depthwise 3x3
 // thread = (pixel, plane of 8 channels); grid (ceil(HW/256), planes, batch)
-template <bool NORM, bool GELU>
+template <bool NORM, bool GELU, int KS>
 __global__ __launch_bounds__(256) void dwconv_kernel(const rsa_dwconv_params p) {
+  constexpr int R = KS / 2, KK = KS * KS;
   const int64_t HW = (int64_t)p.H * p.W;
   const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int pl = blockIdx.y, n = blockIdx.z;
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const rsa_dwconv_params p) 
   const int y = (int)(pix / p.W), x = (int)(pix - (int64_t)y * p.W);
   const bf16x8* in_hi = (const bf16x8*)p.in_hi + (int64_t)n * p.in_batch_stride + (int64_t)pl * p.in_plane_stride;
   const bf16x8* in_lo = p.in_lo ? (const bf16x8*)p.in_lo + (int64_t)n * p.in_batch_stride + (int64_t)pl * p.in_plane_stride : nullptr;
-  const float* wt = p.weight + pl * 72;
+  const float* wt = p.weight + pl * 8 * KK;
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = p.bias[pl * 8 + j];
@@ -424,9 +425,9 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const rsa_dwconv_params p) 
     }
   }
 #pragma unroll
-  for (int dy = -1; dy <= 1; ++dy)
+  for (int dy = -R; dy <= R; ++dy)
 #pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) {
+    for (int dx = -R; dx <= R; ++dx) {
       const int yy = y + dy, xx = x + dx;
       if (yy < 0 || yy >= p.H || xx < 0 || xx >= p.W) continue;
       const int64_t q = (int64_t)yy * p.W + xx;
@@ -437,9 +438,9 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const rsa_dwconv_params p) 
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (v[j] - mean) * rstd * gam[j] + bet[j];
       }
-      const int tap = (dy + 1) * 3 + dx + 1;
+      const int tap = (dy + R) * KS + dx + R;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += wt[j * 9 + tap] * v[j];
+      for (int j = 0; j < 8; ++j) acc[j] += wt[j * KK + tap] * v[j];
     }
   if (GELU) {
 #pragma unroll
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(256) void channel_gate_kernel(const rsa_channel_gat
   for (int c = threadIdx.x; c < C; c += 256) {
     float s = p.b2[c];
     for (int k = 0; k < p.hidden; ++k) s += p.w2[(int64_t)c * p.hidden + k] * s_hid[k];
-    p.gate[(int64_t)n * C + c] = sigmoidf(s);
+    p.gate[(int64_t)n * C + c] = p.relu == 2 ? fminf(fmaxf(s * (1.f / 6.f) + 0.5f, 0.f), 1.f) : sigmoidf(s);
   }
 }
 
@@ -713,14 +714,28 @@ extern "C" int rsa_dwconv3x3(const rsa_dwconv_params* p, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const bool gelu = p->act == RSA_ACT_GELU;
   if (p->stats) {
-    if (gelu) hipLaunchKernelGGL((dwconv_kernel<true, true>), grid, block, 0, s, *p);
-    else hipLaunchKernelGGL((dwconv_kernel<true, false>), grid, block, 0, s, *p);
+    if (gelu) hipLaunchKernelGGL((dwconv_kernel<true, true, 3>), grid, block, 0, s, *p);
+    else hipLaunchKernelGGL((dwconv_kernel<true, false, 3>), grid, block, 0, s, *p);
   } else {
-    if (gelu) hipLaunchKernelGGL((dwconv_kernel<false, true>), grid, block, 0, s, *p);
-    else hipLaunchKernelGGL((dwconv_kernel<false, false>), grid, block, 0, s, *p);
+    if (gelu) hipLaunchKernelGGL((dwconv_kernel<false, true, 3>), grid, block, 0, s, *p);
+    else hipLaunchKernelGGL((dwconv_kernel<false, false, 3>), grid, block, 0, s, *p);
   }
   const hipError_t rc = hipGetLastError();
   return rc ? set_error(rc, "dwconv3x3: launch failed") : RSA_OK;
+}
+
+extern "C" int rsa_dwconv5x5(const rsa_dwconv_params* p, void* stream) {
+  if (p == nullptr) return set_error(RSA_E_ARG, "dwconv5x5: null params");
+  if (p->batch < 1 || p->H < 1 || p->W < 1 || p->planes < 1 || p->planes > 65535 || p->batch > 65535) return set_error(RSA_E_ARG, "dwconv5x5: bad geometry");
+  if (p->act != RSA_ACT_NONE || p->stats != nullptr) return set_error(RSA_E_UNSUPPORTED, "dwconv5x5: no activation / normalisation variant is compiled");
+  if (!p->in_hi || !p->weight || !p->bias || !p->out_hi) return set_error(RSA_E_ARG, "dwconv5x5: null pointer");
+  if (misaligned(p->in_hi) || misaligned(p->in_lo) || misaligned(p->mul_hi) || misaligned(p->mul_lo) || misaligned(p->out_hi) || misaligned(p->out_lo))
+    return set_error(RSA_E_ALIGN, "dwconv5x5: maps must be 16-byte aligned");
+  const int64_t HW = (int64_t)p->H * p->W;
+  hipLaunchKernelGGL((dwconv_kernel<false, false, 5>), dim3((unsigned)((HW + 255) / 256), (unsigned)p->planes, (unsigned)p->batch), dim3(256), 0,
+                     (hipStream_t)stream, *p);
+  const hipError_t rc = hipGetLastError();
+  return rc ? set_error(rc, "dwconv5x5: launch failed") : RSA_OK;
 }
 
 extern "C" int rsa_plane_stats(const void* in_hi, const void* in_lo, int64_t plane_stride, int64_t batch_stride, int32_t batch, int32_t H, int32_t W,

@@ -57,6 +57,9 @@ class ConvParams(C.Structure):
         ('out_shift', C.c_void_p),
         ('act_vec', C.c_void_p),
         ('out_base', C.c_void_p),
+        ('out_base_div', C.c_int32),
+        ('out_base_h', C.c_int32),
+        ('out_base_w', C.c_int32),
     ]
 
 
@@ -231,6 +234,32 @@ class ChannelGateParams(C.Structure):
     ]
 
 
+class GatedShuffleParams(C.Structure):
+    """Mirror of ``struct rsa_gated_shuffle_params``."""
+
+    _fields_ = [
+        ('batch', C.c_int32),
+        ('H', C.c_int32),
+        ('W', C.c_int32),
+        ('g_planes', C.c_int32),
+        ('i_planes', C.c_int32),
+        ('f_hi', C.c_void_p),
+        ('f_lo', C.c_void_p),
+        ('f_plane_stride', C.c_int64),
+        ('f_batch_stride', C.c_int64),
+        ('c_hi', C.c_void_p),
+        ('c_lo', C.c_void_p),
+        ('c_plane_stride', C.c_int64),
+        ('c_batch_stride', C.c_int64),
+        ('gate', C.c_void_p),
+        ('gate_stride', C.c_int64),
+        ('out_hi', C.c_void_p),
+        ('out_lo', C.c_void_p),
+        ('out_plane_stride', C.c_int64),
+        ('out_batch_stride', C.c_int64),
+    ]
+
+
 class AimParams(C.Structure):
     """Mirror of ``struct rsa_aim_params``."""
 
@@ -283,6 +312,10 @@ EXPORTS = (
     'rsa_channel_gate',
     'rsa_aim_combine',
     'rsa_gated_add',
+    'rsa_dwconv5x5',
+    'rsa_rmsnorm',
+    'rsa_unshuffle_pool',
+    'rsa_gated_shuffle_mul',
     'rsa_image_u8_to_nchw',
     'rsa_nchw_to_image_u8',
 )
@@ -343,6 +376,16 @@ def load() -> C.CDLL:
     lib.rsa_plane_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
                                     C.c_void_p]  # fmt: skip
     lib.rsa_plane_stats.restype = C.c_int
+    lib.rsa_dwconv5x5.argtypes = [C.POINTER(DwConvParams), C.c_void_p]
+    lib.rsa_dwconv5x5.restype = C.c_int
+    lib.rsa_gated_shuffle_mul.argtypes = [C.POINTER(GatedShuffleParams), C.c_void_p]
+    lib.rsa_gated_shuffle_mul.restype = C.c_int
+    lib.rsa_rmsnorm.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_int64, C.c_int64, C.c_void_p]  # fmt: skip
+    lib.rsa_rmsnorm.restype = C.c_int
+    lib.rsa_unshuffle_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]  # fmt: skip
+    lib.rsa_unshuffle_pool.restype = C.c_int
     lib.rsa_gated_add.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_float,
                                   C.c_void_p, C.c_void_p, C.c_void_p]  # fmt: skip
     lib.rsa_gated_add.restype = C.c_int

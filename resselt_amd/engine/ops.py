@@ -81,6 +81,7 @@ def conv_params(
     out_shift: torch.Tensor | None = None,
     act_vec: torch.Tensor | None = None,
     out_base: torch.Tensor | None = None,
+    out_base_div: int = 0,
 ) -> L.ConvParams:
     """Fill one ``rsa_conv_params``. ``H``, ``W`` are the OUTPUT size of the convolution."""
     p = L.ConvParams()
@@ -138,9 +139,12 @@ def conv_params(
         p.out_dtype = rsa_dtype(out_nchw.dtype)
         p.out_shift = None if out_shift is None else out_shift.data_ptr()
         if out_base is not None:
-            if tuple(out_base.shape) != (x.n, exp[1], H, W) or out_base.dtype != out_nchw.dtype or not out_base.is_contiguous():
-                raise ValueError('out_base must be a contiguous [N, C_out, H, W] tensor of the output dtype')
+            if out_base.dim() != 4 or tuple(out_base.shape[:2]) != (x.n, exp[1]) or out_base.dtype != out_nchw.dtype or not out_base.is_contiguous():
+                raise ValueError('out_base must be a contiguous [N, C_out, h, w] tensor of the output dtype')
+            if out_base_div == 0 and tuple(out_base.shape[2:]) != (H, W):
+                raise ValueError('out_base must be H x W unless out_base_div gives the nearest-upsampling factor')
             p.out_base = out_base.data_ptr()
+            p.out_base_div, p.out_base_h, p.out_base_w = out_base_div, out_base.shape[2], out_base.shape[3]
     if act == L.ACT_PRELU:
         if act_vec is None or act_vec.numel() < ((wts.cout + 15) // 16) * 16 or act_vec.dtype != torch.float32:
             raise ValueError('PReLU needs f32 slopes padded to a multiple of 16')

@@ -93,3 +93,20 @@ def test_compact_matches_reference_vectors(device, name):
     assert (y.cpu() - arr['y']).abs().max().item() <= _tol(arr['y'])
     yh = m(arr['x'].half().to(device))
     assert yh.dtype == torch.float16 and (yh.float().cpu() - arr['y']).abs().max().item() <= 4e-3 * max(1.0, arr['y'].abs().max().item())
+
+
+@pytest.mark.parametrize('name', golden_names('rtmosr_'))
+def test_rtmosr_matches_reference_vectors(device, name):
+    """RTMoSR (RMSNorm, gated block with unshuffle / max-pool / depthwise 5x5 / SE branch, nearest-upsampled base image) vs the reference in eval mode."""
+    meta, arr = load_golden(name)
+    sd = synth_state_dict(meta)
+    m = resselt_amd.load_from_state_dict(dict(sd)).to(device)
+    assert vars(m.parameters_info) == {k: meta['metadata'][k] for k in ('in_channels', 'out_channels', 'upscale', 'name')}
+    y = m(arr['x'].to(device))
+    torch.cuda.synchronize()
+    assert y.shape == arr['y'].shape
+    err = (y.cpu() - arr['y']).abs().max().item()
+    print(f'{name}: max-abs {err:.3e}')
+    assert err <= _tol(arr['y']), f'{name}: max-abs {err:.3e} (|y|max {arr["y"].abs().max():.3f})'
+    yh = m(arr['x'].to(device).half())
+    assert yh.dtype == torch.float16 and (yh.float().cpu() - arr['y']).abs().max().item() <= 10 * _tol(arr['y'])

@@ -34,6 +34,8 @@ def main():
                                                      upsampler=rng.choice(['nearest+conv', 'pixelshuffle', 'pixelshuffledirect']), seed=s), 9),
         'dat': lambda s: (synth.dat_state_dict(embed_dim=64, depth=(3,), num_heads=(4,), split_size=rng.choice([(2, 4), (4, 8), (8, 8)]),
                                                upscale=rng.choice([2, 3]), img_size=16, seed=s), 2),
+        'rtmosr': lambda s: (synth.rtmosr_state_dict(scale=rng.choice([2, 4]), dim=rng.choice([32, 48]), n_blocks=2, se=rng.random() < 0.6,
+                                                     dccm=rng.random() < 0.7, seed=s), 3),
         'hat': lambda s: (synth.hat_state_dict(embed_dim=60, depths=(2,), num_heads=(6,), window=rng.choice([4, 8]), upscale=rng.choice([2, 4]), seed=s), 9),
     }  # fmt: skip
     worst = 0.0
