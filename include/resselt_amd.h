@@ -330,7 +330,7 @@ typedef struct rsa_channel_gate_params {
   int32_t batch;
   int32_t H, W;
   int32_t planes;            /* C = 8*planes (pad channels carry zero weights) */
-  int32_t hidden;            /* <= 64 */
+  int32_t hidden;            /* <= 128 */
   const void* in_hi;
   const void* in_lo;         /* may be NULL */
   int64_t in_plane_stride;

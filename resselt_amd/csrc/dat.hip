@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const rsa_channel_gate
 // grid (batch), 256 threads
 __global__ __launch_bounds__(256) void channel_gate_kernel(const rsa_channel_gate_params p, int chunks) {
   __shared__ float s_mean[512];
-  __shared__ float s_hid[64];
+  __shared__ float s_hid[128];
   const int n = blockIdx.x;
   const int C = p.planes * 8;
   const float inv = 1.f / (float)((int64_t)p.H * p.W);
@@ -757,8 +757,8 @@ extern "C" int64_t rsa_channel_gate_workspace_bytes(int32_t batch, int32_t H, in
 
 extern "C" int rsa_channel_gate(const rsa_channel_gate_params* p, void* stream) {
   if (p == nullptr) return set_error(RSA_E_ARG, "channel_gate: null params");
-  if (p->batch < 1 || p->batch > 65535 || p->H < 1 || p->W < 1 || p->planes < 1 || p->planes > 64 || p->hidden < 1 || p->hidden > 64)
-    return set_error(RSA_E_ARG, "channel_gate: bad geometry (planes <= 64, hidden <= 64)");
+  if (p->batch < 1 || p->batch > 65535 || p->H < 1 || p->W < 1 || p->planes < 1 || p->planes > 64 || p->hidden < 1 || p->hidden > 128)
+    return set_error(RSA_E_ARG, "channel_gate: bad geometry (planes <= 64, hidden <= 128)");
   if (!p->in_hi || !p->w1 || !p->b1 || !p->w2 || !p->b2 || !p->workspace || !p->gate) return set_error(RSA_E_ARG, "channel_gate: null pointer");
   if (misaligned(p->in_hi) || misaligned(p->in_lo)) return set_error(RSA_E_ALIGN, "channel_gate: maps must be 16-byte aligned");
   const int64_t chunks = ((int64_t)p->H * p->W + CG_PIX - 1) / CG_PIX;
