@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Randomised parity sweep on the GPU: every architecture x odd sizes x batch x tensor dtype against the CPU oracle.
+"""(Lives under tests/: like the test-suite it uses the CPU oracle as the checker.)
 
-usage: python tools/fuzz_parity.py [seed] [cases_per_arch]   -> one line per case, non-zero exit status on the first failure
+Randomised parity sweep on the GPU: every architecture x odd sizes x batch x tensor dtype against the CPU oracle.
+
+usage: python tests/fuzz_parity.py [seed] [cases_per_arch]   -> one line per case, non-zero exit status on the first failure
 """
 
 import os

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Parity at (or near) the BASELINE config sizes (SURVEY.md §8d "Parity"): max-abs and mean-abs error of the GPU engine against the
+"""(Lives under tests/: like the test-suite it uses the CPU oracle as the checker.)
+
+Parity at (or near) the BASELINE config sizes (SURVEY.md §8d "Parity"): max-abs and mean-abs error of the GPU engine against the
 fp32 CPU oracle on identical synthetic weights and inputs, per config and per precision mode.  One JSON line per (config, mode).
 
 For 16-bit tensor I/O the figures include the rounding of the OUTPUT tensor to that dtype (half an ulp at |y|max: 2.4e-4*|y| for fp16,
