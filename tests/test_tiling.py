@@ -72,26 +72,28 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_tile_parallel_all_gather_gloo():
+@pytest.mark.parametrize('world', [2, 4])
+def test_tile_parallel_all_gather_gloo(world):
+    """world_size 2 and 4 over gloo: one tile per rank (N x 1 and the chooser's grid), uneven tiles, fewer tiles than ranks."""
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = dict()
-    for _ in range(2):
-        rank, y, y3, y1 = q.get(timeout=120)
+    for _ in range(world):
+        rank, y, y3, y1 = q.get(timeout=180)
         results[rank] = (y.clone(), y3.clone(), y1.clone())
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     model = _model()
     full = model(synth.synth_input((1, 3, 40, 52), seed=9))
-    for rank in (0, 1):
+    for rank in range(world):
         y, y3, y1 = results[rank]
         assert y.shape == full.shape
         assert (y - full).abs().max().item() <= 1e-6, rank  # every rank ends with the whole image
