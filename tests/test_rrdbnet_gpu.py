@@ -141,3 +141,22 @@ def test_uint8_image_round_trip_and_upscale_helper(device):
     assert torch.equal(one, manual)
     tiled = upscale(m, img[0].to(device), tile=(24, 32), halo=16, dtype=torch.float32)
     assert (tiled.int() - one.int()).abs().max().item() <= 1  # nb=2: receptive field < halo, so at most a rounding tie
+
+
+def test_graph_replay_matches_eager(device):
+    """use_graph: the forward captured once as a hipGraph and replayed; same values as the eager launch list, new inputs take effect."""
+    sd = synth.rrdbnet_state_dict(nb=3, scale=4, seed=12)
+    m = resselt_amd.load_from_state_dict(dict(sd)).to(device)
+    x1, x2 = synth.synth_input((1, 3, 40, 56), seed=1).to(device), synth.synth_input((1, 3, 40, 56), seed=2).to(device)
+    e1, e2 = m(x1).clone(), m(x2).clone()
+    m.use_graph = True
+    g1 = m(x1)
+    g2 = m(x2)
+    g1b = m(x1)
+    torch.cuda.synchronize()
+    assert torch.equal(g1, e1) and torch.equal(g2, e2) and torch.equal(g1b, e1)
+    sd2 = synth.compact_state_dict(num_feat=32, num_conv=3, upscale=2, seed=4)  # the final store of this model reads the INPUT as a base image
+    c = resselt_amd.load_from_state_dict(dict(sd2)).to(device)
+    ec = c(x2).clone()
+    c.use_graph = True
+    assert torch.equal(c(x1), c(x1)) and torch.equal(c(x2), ec)
