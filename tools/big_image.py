@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""C5-scale input on ONE GPU through the tiling driver: RealESRGAN-x4plus on a 4320x7680 frame (16 tiles of 1080p + 32 px halo)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import resselt_amd  # noqa: E402
+from resselt_amd.tiling import upscale_tiled  # noqa: E402
+from resselt_amd.utils import synth  # noqa: E402
+
+dev = torch.device('cuda:0')
+h, w = (int(v) for v in (sys.argv[1:3] if len(sys.argv) > 2 else (4320, 7680)))
+model = resselt_amd.load_from_state_dict(dict(synth.rrdbnet_state_dict(nb=23))).to(dev)
+x = synth.synth_input((1, 3, h, w)).to(dev)
+upscale_tiled(model, x[:, :, :1080, :1920], 4, (1080, 1920), halo=32)  # warm-up: packing + plan
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+y = upscale_tiled(model, x, 4, (1080, 1920), halo=32)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(f'RRDBNet-23 x4 {h}x{w} -> {tuple(y.shape)} in {dt:.2f} s = {y.shape[2] * y.shape[3] / 1e6 / dt:.1f} output MP/s on one MI355X; '
+      f'peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB; finite {bool(torch.isfinite(y[:, :, ::64, ::64]).all())}')
