@@ -184,8 +184,6 @@ class SwinIR(EngineModule):
             raise NotImplementedError('SwinIR engine supports patch_size=1, ape=False, qkv_bias=True, default qk scale (what the loader builds)')
         if start_unshuffle != 1:
             raise NotImplementedError('start_unshuffle > 1 cannot load in the reference either (SURVEY.md §4 defect 6)')
-        if upsampler == '':
-            raise NotImplementedError("SwinIR denoising / JPEG heads (upsampler '') are outside this build's scope (SURVEY.md §8)")
         if window_size > 8:
             raise NotImplementedError('window_size must be <= 8 (64 tokens per window)')
         if min(img_size, img_size) <= window_size:
@@ -302,8 +300,11 @@ class SwinIR(EngineModule):
         x_pl = plan.planes(n, (c + 7) // 8, H, Wd, with_lo)
         mean = W['mean']
 
+        holder = {}
+
         def set_input(x):
             # check_image_size (reflect pad to the window multiple) and (x - mean) * img_range, fused (arch.py:964-967)
+            holder['x'] = x
             ops.nchw_to_planes(x, x_pl, mean, self.img_range)
 
         first = plan.f32map(n, C_, H, Wd)
@@ -421,8 +422,14 @@ class SwinIR(EngineModule):
                 y = ny
                 i += 2
             plan.conv(ops.conv_params(W['conv_last'], y, hh, ww, out_nchw=out_buf['y'], **final))
-        else:  # pixelshuffledirect
+        elif self.upsampler == 'pixelshuffledirect':
             plan.conv(ops.conv_params(W['upsample.0'], body_pl, H, Wd, cin_planes=cp, out_nchw=out_buf['y'], pixel_shuffle=s, **final))
+        else:
+            # denoising / JPEG artefact heads (arch.py:1007-1010): (x_norm + conv_last(res)) / img_range + mean == x + conv_last(res) / img_range,
+            # so the final store scales the convolution and adds the caller's own (unpadded) input as the base image
+            base0 = torch.empty((n, self.in_chans, h0, w0), dtype=dtype, device=dev)  # placeholder pointer, patched per call
+            plan.conv(ops.conv_params(W['conv_last'], body_pl, H, Wd, cin_planes=cp, out_nchw=out_buf['y'], out_scale=1.0 / self.img_range,
+                                      out_base=base0, out_base_div=1))  # fmt: skip
         arr = plan.flush()
         last_entry = arr[len(arr) - 1]
 
@@ -430,10 +437,13 @@ class SwinIR(EngineModule):
             if 'y' not in out_buf:
                 out_buf['y'] = torch.empty(out_shape, dtype=dtype, device=dev)
             last_entry.out_nchw = out_buf['y'].data_ptr()
+            if self.upsampler == '':
+                last_entry.out_base = holder['x'].data_ptr()
 
         plan.steps.insert(len(plan.steps) - 1, prepare_output)
 
         def get_output():
+            holder.clear()
             return out_buf.pop('y')[:, :, : h0 * s, : w0 * s]
 
         return set_input, get_output

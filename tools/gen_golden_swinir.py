@@ -15,6 +15,9 @@ def swinir_cases(save, meta_of):
         ('swinir_M_like_ps_x2_19x30', dict(embed_dim=180, depths=[2], num_heads=[6], upscale=2, upsampler='pixelshuffle', resi='1conv'), (1, 3, 19, 30), 52),
         # lightweight head (pixelshuffledirect), embed 60, batch 2, 3 blocks (shifted block last)
         ('swinir_S_like_psd_x3_b2_16x16', dict(embed_dim=60, depths=[3], num_heads=[6], upscale=3, upsampler='pixelshuffledirect', resi='1conv'), (2, 3, 16, 16), 53),
+        # restoration heads (upsampler ''): grey denoising (1 channel, window 8) and the JPEG wiring (window 7 -> img_range 255, img_size 126)
+        ('swinir_dn_gray_19x21', dict(in_ch=1, embed_dim=60, depths=[2], num_heads=[6], upscale=1, upsampler='', resi='1conv', img_size=128), (1, 1, 19, 21), 55),
+        ('swinir_jpeg_w7_b2_20x23', dict(embed_dim=96, depths=[2, 2], num_heads=[6, 6], window=7, upscale=1, upsampler='', resi='1conv', img_size=126), (2, 3, 20, 23), 56),
         ('swinir_x8_nearest_8x16', dict(embed_dim=64, depths=[2], num_heads=[2], upscale=8, upsampler='nearest+conv', resi='1conv'), (1, 3, 8, 16), 54),
     ]
     for name, kw, shape, seed in cases:
