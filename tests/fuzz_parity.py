@@ -34,6 +34,8 @@ def main():
         'compact': lambda s: (synth.compact_state_dict(num_feat=rng.choice([32, 64]), num_conv=rng.choice([2, 5]), upscale=rng.choice([2, 4]), seed=s), 1),
         'swinir': lambda s: (synth.swinir_state_dict(embed_dim=60, depths=(2, 2), num_heads=(6, 6), upscale=rng.choice([2, 4]),
                                                      upsampler=rng.choice(['nearest+conv', 'pixelshuffle', 'pixelshuffledirect']), seed=s), 9),
+        'swinir_restore': lambda s: ((lambda w7: synth.swinir_state_dict(in_ch=rng.choice([1, 3]), embed_dim=60, depths=(2, 2), num_heads=(6, 6), upscale=1,
+                                                                         upsampler='', window=7 if w7 else 8, img_size=126 if w7 else 64, seed=s))(rng.random() < 0.5), 9),
         'dat': lambda s: (synth.dat_state_dict(embed_dim=64, depth=(3,), num_heads=(4,), split_size=rng.choice([(2, 4), (4, 8), (8, 8)]),
                                                upscale=rng.choice([2, 3]), img_size=16, seed=s), 2),
         'rtmosr': lambda s: (synth.rtmosr_state_dict(scale=rng.choice([2, 4]), dim=rng.choice([32, 48]), n_blocks=2, se=rng.random() < 0.6,
@@ -48,9 +50,10 @@ def main():
             n = rng.choice([1, 1, 2, 3])
             h, w = rng.randint(min_hw, 45), rng.randint(min_hw, 45)
             dt = rng.choice([torch.float32, torch.float32, torch.float16, torch.bfloat16])
-            x = synth.synth_input((n, 3, h, w), seed=s).to(dt)
+            cin = sd['conv_first.weight'].shape[1] if arch == 'swinir_restore' else 3
+            x = synth.synth_input((n, cin, h, w), seed=s).to(dt)
             with torch.no_grad():
-                ref = oracle_forward(dict(arch=arch), sd, x.float())
+                ref = oracle_forward(dict(arch=arch.split('_')[0]), sd, x.float())
             model = resselt_amd.load_from_state_dict(dict(sd)).to(dev)
             xd = x.to(dev)
             if rng.random() < 0.3:  # a non-contiguous view of the same values
@@ -62,7 +65,7 @@ def main():
             err = (y.float().cpu() - ref).abs().max().item()
             ok = y.shape == ref.shape and y.dtype == dt and err <= tol
             worst = max(worst, err / tol)
-            print(f'{arch:9s} n={n} {h:2d}x{w:2d} {str(dt).split(".")[-1]:8s} -> {tuple(y.shape)} max-abs {err:.2e} (tol {tol:.1e}) {"ok" if ok else "FAIL"}', flush=True)
+            print(f'{arch:14s} n={n} {h:2d}x{w:2d} {str(dt).split(".")[-1]:8s} -> {tuple(y.shape)} max-abs {err:.2e} (tol {tol:.1e}) {"ok" if ok else "FAIL"}', flush=True)
             if not ok:
                 raise SystemExit(1)
             del model
