@@ -1,6 +1,6 @@
 // conv_inst_k3p3u1.hip — instantiations of conv_kernel<KS=3, NCT, PROD=3, UP=1, OUTK> (own translation unit: parallel compile).
-#include "conv_kernel.h"
+#include "conv_kernel_pp.h"
 
 namespace rsa {
-int conv_launch_k3p3u1(const rsa_conv_params& p, int nct, hipStream_t stream) { return launch_nct<3, 3, 1>(p, nct, stream); }
+int conv_launch_k3p3u1(const rsa_conv_params& p, int nct, hipStream_t stream) { return launch_nct_pp<3, 3, 1>(p, nct, stream); }
 }  // namespace rsa
