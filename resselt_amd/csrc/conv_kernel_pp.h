@@ -1,18 +1,21 @@
 // conv_kernel_pp.h — alternating ("ping-pong") schedule of the fused 3x3 convolution for layers with at most two cout tiles
 // (Cout <= 32: the four growth convolutions of every residual dense block, utilities/block.py:454-465 of the reference).
 //
-// Why: with all eight compute waves on ONE tile (conv_kernel.h) every wave reaches the epilogue at the same moment; the matrix
-// pipes idle while the stores are issued, and the first weight loads of the next tile queue (vmcnt retires in order) behind those
-// stores.  Here the eight compute waves form two groups of four (one wave per SIMD each).  Group g owns every second tile of the
-// workgroup and LDS buffer g; the groups take turns chunk by chunk:
+// Why: with all eight compute waves in lock step on ONE tile (conv_kernel.h) every wave reaches the epilogue at the same moment; the
+// matrix pipes idle while the stores are issued, and the first weight loads of the next tile queue (vmcnt retires in order) behind
+// those stores.  Here the eight compute waves form two groups of four (one wave per SIMD each: waves 0-3 and 4-7).  Group g owns
+// every second tile of the workgroup and LDS buffer g, and the groups take turns, one workgroup barrier per phase:
 //
-//   phase h (one workgroup barrier each):  group (h & 1) multiplies its chunk out of buffer (h & 1)
-//                                          the loader wave fills buffer (h+1) & 1 with the other group's next chunk
-//                                          the other group stores the tile it finished one phase ago (if any)
+//   phase h:  group (h & 1) multiplies one 32-channel chunk of its tile out of buffer h & 1
+//             (16 accumulator tiles per wave: 4 rows x 2 halves x 2 cout tiles);
+//             the other group stores the tile it finished one phase ago (if any), then waits;
+//             the loader wave streams the other group's next chunk into buffer (h+1) & 1.
 //
 // so a group's epilogue, and the drain of its stores, lie under the other group's MFMA phase.  The loader protocol is the one of
 // conv_kernel.h (item h into buffer h & 1 while item h-1 is multiplied); only the item order differs (the two tiles interleaved).
-// A wave owns 4 rows x 2 halves x 2 cout tiles = 16 accumulator tiles (the per-wave shape of the 4-cout-tile geometry).
+// Measured on the 1080p RRDBNet-23 frame: 222 -> 208 ms.  The same alternation for the four-cout-tile layers (the groups taking the
+// two cout halves of one tile in turn) was built and is 2 % slower than conv_kernel: those layers are MFMA-bound and lose more from
+// having one instead of two waves per SIMD in the multiply than they gain from the hidden epilogue (rejected list).
 #pragma once
 #include <stdlib.h>
 
@@ -30,7 +33,7 @@ __global__ __launch_bounds__(576, 3) void conv_kernel_pp(const rsa_conv_params p
   constexpr int DMA_IT = (ACT_UNITS + 63) / 64;
   constexpr int T = KS * KS;
 
-  __shared__ uint4 s_act[2][NHL * ACT_UNITS];  // buffer g belongs to group g
+  __shared__ uint4 s_act[2][NHL * ACT_UNITS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -48,16 +51,15 @@ __global__ __launch_bounds__(576, 3) void conv_kernel_pp(const rsa_conv_params p
   const int NWG = (int)gridDim.x;
   const int tile0 = (NWG % 8 == 0) ? ((int)blockIdx.x % 8) * (NWG / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;  // XCD strips, as conv_kernel
   if (tile0 >= num_tiles) return;
-  const int ntw = (num_tiles - tile0 + NWG - 1) / NWG;  // tiles of this workgroup: tile0 + j*NWG, j = 0 .. ntw-1; group g owns j = g (mod 2)
-  const int npairs = (ntw + 1) >> 1;
-  // phases: 2 per (pair, chunk) + one trailing phase in which group 1 stores its last tile
-  const int nphases = 2 * npairs * nchunks + 1;
+  const int ntw = (num_tiles - tile0 + NWG - 1) / NWG;  // tiles of this workgroup: tile0 + j*NWG, j = 0 .. ntw-1
+  // phases: two per (tile pair, chunk) + one trailing phase in which group 1 stores its last tile
+  const int nphases = 2 * ((ntw + 1) >> 1) * nchunks + 1;
 
   if (wave == 8) {
     // =========================== LOADER WAVE ===========================
-    // Streams phase h's item into buffer h & 1 while phase h-1 is multiplied (the protocol of conv_kernel.h).  Two tiles are live at
-    // once, so the per-tile source map is not kept in registers: each lane keeps the tile-independent part (plane, row, column of
-    // its unit in every DMA instruction, packed) and applies the tile origin, the bounds and the nearest-x2 read per item.
+    // Two tiles can be live at once, so the per-tile source map is not kept in registers: each lane keeps the tile-independent
+    // part (plane, row, column of its unit in every DMA instruction, packed) and applies the tile origin, the bounds, the zero
+    // padding (a zero page) and the nearest-x2 read per item.
     const uint32_t plane_units = (uint32_t)p.in_plane_stride;
     uint32_t smap[DMA_IT];
 #pragma unroll
@@ -69,82 +71,77 @@ __global__ __launch_bounds__(576, 3) void conv_kernel_pp(const rsa_conv_params p
       const int px = r - py * IW;
       smap[it] = (r < IH * IW) ? (uint32_t)(pl << 16 | py << 8 | px) : 0xFFFFFFFFu;
     }
-    for (int h = 0; h < nphases; ++h) {
-      const int g = h & 1, idx = h >> 1;
-      const int jp = idx / nchunks;
-      const int q = idx - jp * nchunks;
-      const int j = 2 * jp + g;
-      if (h < nphases - 1 && j < ntw) {
-        const int planes_left = p.cin_planes - q * NPL;
-        const int tile = tile0 + j * NWG;
-        const int n = tile / tiles_img;
-        const int tr = tile - n * tiles_img;
-        const int ty = tr / tiles_x;
-        const int tx = tr - ty * tiles_x;
-        const int y0 = ty * TH - HALO, x0 = tx * TW - HALO;
-        const uint4* ch = (const uint4*)p.in_hi + (int64_t)n * p.in_batch_stride + (int64_t)q * NPL * p.in_plane_stride;
-        const uint4* cl = (PROD == 3) ? (const uint4*)p.in_lo + (int64_t)n * p.in_batch_stride + (int64_t)q * NPL * p.in_plane_stride : nullptr;
-        uint4* dst = &s_act[g][0];
+    auto fill = [&](int j, int q, int buf) {  // chunk q of the workgroup's tile j -> LDS buffer buf
+      const int planes_left = p.cin_planes - q * NPL;
+      const int tile = tile0 + j * NWG;
+      const int n = tile / tiles_img;
+      const int tr = tile - n * tiles_img;
+      const int ty = tr / tiles_x;
+      const int tx = tr - ty * tiles_x;
+      const int y0 = ty * TH - HALO, x0 = tx * TW - HALO;
+      const uint4* ch = (const uint4*)p.in_hi + (int64_t)n * p.in_batch_stride + (int64_t)q * NPL * p.in_plane_stride;
+      const uint4* cl = (PROD == 3) ? (const uint4*)p.in_lo + (int64_t)n * p.in_batch_stride + (int64_t)q * NPL * p.in_plane_stride : nullptr;
+      uint4* dst = &s_act[buf][0];
 #pragma unroll
-        for (int it = 0; it < DMA_IT; ++it) {
-          const uint32_t m = smap[it];
-          const int pl = (int)(m >> 16);
-          int iy = y0 + (int)((m >> 8) & 255u), ix = x0 + (int)(m & 255u);
-          const bool ok = m != 0xFFFFFFFFu && (uint32_t)iy < (uint32_t)p.H && (uint32_t)ix < (uint32_t)p.W && pl < planes_left;
-          if (UP) {
-            iy >>= 1;
-            ix >>= 1;
-          }
-          const uint32_t off = (uint32_t)pl * plane_units + (uint32_t)iy * (uint32_t)inW + (uint32_t)ix;
-          const uint4* sh = ok ? ch + off : (const uint4*)&g_zero_unit[0];
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sh,
-                                           (__attribute__((address_space(3))) void*)(dst + it * 64), 16, 0, 0);
-          if (PROD == 3) {
-            const uint4* sl = ok ? cl + off : (const uint4*)&g_zero_unit[0];
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sl,
-                                             (__attribute__((address_space(3))) void*)(dst + ACT_UNITS + it * 64), 16, 0, 0);
-          }
+      for (int it = 0; it < DMA_IT; ++it) {
+        const uint32_t m = smap[it];
+        const int pl = (int)(m >> 16);
+        int iy = y0 + (int)((m >> 8) & 255u), ix = x0 + (int)(m & 255u);
+        const bool ok = m != 0xFFFFFFFFu && (uint32_t)iy < (uint32_t)p.H && (uint32_t)ix < (uint32_t)p.W && pl < planes_left;
+        if (UP) {
+          iy >>= 1;
+          ix >>= 1;
+        }
+        const uint32_t off = (uint32_t)pl * plane_units + (uint32_t)iy * (uint32_t)inW + (uint32_t)ix;
+        const uint4* sh = ok ? ch + off : (const uint4*)&g_zero_unit[0];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sh,
+                                         (__attribute__((address_space(3))) void*)(dst + it * 64), 16, 0, 0);
+        if (PROD == 3) {
+          const uint4* sl = ok ? cl + off : (const uint4*)&g_zero_unit[0];
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sl,
+                                           (__attribute__((address_space(3))) void*)(dst + ACT_UNITS + it * 64), 16, 0, 0);
         }
       }
-      dma_wait();
-      wg_barrier();  // phase h starts: buffer h & 1 is ready
+    };
+    auto issue = [&](int h) {  // phase h's item: chunk (h/2) % nchunks of tile 2*(h/2/nchunks) + (h & 1), into buffer h & 1
+      const int idx = h >> 1;
+      const int jj = idx / nchunks;
+      const int q = idx - jj * nchunks;
+      const int j = 2 * jj + (h & 1);
+      if (j < ntw) fill(j, q, h & 1);
+    };
+    issue(0);
+    for (int h = 0; h < nphases; ++h) {
+      dma_wait();    // this wave's DMA has landed ...
+      wg_barrier();  // ... phase h starts, and the barrier has released the other buffer
+      issue(h + 1);
     }
     return;
   }
 
   // =========================== COMPUTE WAVES ===========================
-#ifdef RSA_PP_GROUP_PARITY
-  const int g = wave & 1;
-  const int wpx = wave >> 1;
-#else
-  const int g = wave >> 2;   // ping-pong group
+  const int g = wave >> 2;   // group: waves 0-3 / 4-7, i.e. one wave of each group per SIMD
   const int wpx = wave & 3;  // group of 4 rows
-#endif
   const int li = lane & 15;
   const int lg = lane >> 4;
 
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.w_packed, 0, (uint32_t)((int64_t)nsteps * ct_total * NHL * 64 * 16), 0x00020000);
-  uint32_t woff[CTW];
+  uint32_t woff[CTW];  // byte offset of this lane's fragment of (step 0, cout tile, hi); 0xFFFFFFFF (-> zeros) when the tile does not exist
 #pragma unroll
-  for (int c = 0; c < CTW; ++c) woff[c] = (c < ct_total) ? (uint32_t)((c * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
+  for (int c = 0; c < CTW; ++c) {
+    woff[c] = (c < ct_total) ? (uint32_t)((c * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
+  }
   const uint32_t wstep = (uint32_t)ct_total * NHL * 64 * 16;
-#ifndef RSA_PP_WDEPTH
-#define RSA_PP_WDEPTH 1
-#endif
-  // Weight ring: WD taps of prefetch in flight.  WD = 2 uses three slots addressed by (tap mod 3) -- 9 taps per chunk keep the slot
-  // of a step fixed across chunks -- and the MFMAs read the ring directly; WD = 1 is conv_kernel's current/next pair with a copy.
-  constexpr int WD = RSA_PP_WDEPTH;
-  constexpr int RING = (WD == 2) ? 3 : 2;
-  static_assert(WD == 1 || (WD == 2 && (KS * KS) % 3 == 0), "weight ring depth");
-  bf16x8 wn[RING][CTW][NHL];
-  auto load_w = [&](int s, int slot) {
+  bf16x8 wc[CTW][NHL];  // fragments of the tap being multiplied
+  bf16x8 wn[CTW][NHL];  // fragments of the next tap, in flight
+  auto load_w = [&](int s) {
 #pragma unroll
     for (int c = 0; c < CTW; ++c)
 #pragma unroll
       for (int hl = 0; hl < NHL; ++hl) {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, woff[c], (uint32_t)s * wstep + (uint32_t)hl * 1024u, 0);
-        wn[slot][c][hl] = __builtin_bit_cast(bf16x8, v);
+        wn[c][hl] = __builtin_bit_cast(bf16x8, v);
       }
   };
 
@@ -155,27 +152,20 @@ __global__ __launch_bounds__(576, 3) void conv_kernel_pp(const rsa_conv_params p
     for (int ct = 0; ct < CTW; ++ct) acc[pt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int bunit0 = lg * PS + (wpx * RPW) * IW + li;
-  const uint4* sa = &s_act[g][0];
 
-#pragma unroll
-  for (int d = 0; d < WD; ++d) load_w(d, d);
-  int pend_tile = -1;  // tile whose accumulators wait for their epilogue
-  int j = g;           // this group's next tile index within the workgroup
-  int q = 0;
+  load_w(0);
+  int pend_tile = -1;        // tile whose accumulators wait for their epilogue
+  int j = g;                 // this group's next tile index within the workgroup
+  int q = 0;                 // its next chunk
+  const uint4* sa = &s_act[g][0];
   for (int h = 0; h < nphases; ++h) {
     wg_barrier();
     if ((h & 1) == g) {
       if (j < ntw) {
-#ifdef RSA_PP_PRIO
-        __builtin_amdgcn_s_setprio(2);
-#endif
-        // ---- multiply chunk q of tile j out of buffer g (software pipeline as in conv_kernel.h, one pixel tile x 2 cout tiles per step) ----
+        // ---- multiply chunk q of tile j (software pipeline as in conv_kernel.h: one pixel tile x 2 cout tiles per step) ----
         constexpr int SPT = NPT;
         constexpr int NSTEP = T * SPT;
-#ifndef RSA_PP_LDSDEPTH
-#define RSA_PP_LDSDEPTH 2
-#endif
-        constexpr int LDS_DEPTH = RSA_PP_LDSDEPTH;
+        constexpr int LDS_DEPTH = 2;
         bf16x8 rh[LDS_DEPTH + 1], rl[LDS_DEPTH + 1];
         auto frag_unit = [&](int i) -> int {
           const int t = i / SPT, pt = i - t * SPT;
@@ -195,10 +185,8 @@ __global__ __launch_bounds__(576, 3) void conv_kernel_pp(const rsa_conv_params p
 #pragma unroll
             for (int c = 0; c < CTW; ++c)
 #pragma unroll
-              for (int hl = 0; hl < NHL; ++hl)
-                if (WD == 1) wn[1][c][hl] = wn[0][c][hl];
-            const int sn = s + WD;
-            load_w(sn < nsteps ? sn : sn - nsteps, WD == 1 ? 0 : (t + WD) % RING);  // past the last step: the first steps of this group's next tile
+              for (int hl = 0; hl < NHL; ++hl) wc[c][hl] = wn[c][hl];
+            load_w(s + 1 < nsteps ? s + 1 : 0);  // next tap; after the last step: step 0 of this group's next tile
             __builtin_amdgcn_sched_barrier(0);
           }
           if (i + LDS_DEPTH < NSTEP) {
@@ -211,8 +199,8 @@ __global__ __launch_bounds__(576, 3) void conv_kernel_pp(const rsa_conv_params p
           for (int pr = 0; pr < NPR; ++pr)
 #pragma unroll
             for (int ct = 0; ct < CTW; ++ct) {
-              const int ws = (WD == 1) ? 1 : t % RING;
-              const bf16x8 wf = (PROD == 3 && pr == 0) ? wn[ws][ct][NHL - 1] : wn[ws][ct][0];
+              // products in increasing magnitude: w_lo*a_hi, w_hi*a_lo, w_hi*a_hi
+              const bf16x8 wf = (PROD == 3 && pr == 0) ? wc[ct][NHL - 1] : wc[ct][0];
               const bf16x8 bf = (PROD == 3 && pr == 1) ? rl[i % (LDS_DEPTH + 1)] : rh[i % (LDS_DEPTH + 1)];
               acc[sp][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, bf, acc[sp][ct], 0, 0, 0);
             }
@@ -220,9 +208,6 @@ __global__ __launch_bounds__(576, 3) void conv_kernel_pp(const rsa_conv_params p
           __builtin_amdgcn_sched_group_barrier(0x008, NPR * CTW, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
-#ifdef RSA_PP_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         if (++q == nchunks) {
           q = 0;
           pend_tile = tile0 + j * NWG;
@@ -266,7 +251,8 @@ static int launch_pp(const rsa_conv_params& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-// Dispatch of the 3x3 families: two-cout-tile layers that fit one slab take the alternating schedule, everything else conv_kernel.
+// Dispatch of the 3x3 families: single-slab layers with at most two cout tiles take the alternating schedule, everything else
+// conv_kernel.  RSA_CONV_PP=0 in the environment switches it off (A/B runs).
 template <int KS, int PROD, int UP>
 static int launch_nct_pp(const rsa_conv_params& p, int nct, hipStream_t stream) {
   static const bool use_pp = [] {
