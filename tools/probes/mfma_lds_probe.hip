@@ -1,6 +1,7 @@
 // mfma_lds_probe.hip — the conv kernels' inner step in isolation: 6 MFMAs (2 cout tiles x 3 products) per pair of ds_read_b128
 // (hi and lo fragment of one pixel tile), fragments prefetched DEPTH steps ahead, weights constant in registers, LDS filled once
-// with pseudo-random bf16.  Compares against the same MFMA stream without the LDS reads (READS = 0).
+// with pseudo-random bf16.  Compares against the same MFMA stream without the LDS reads (READS = 0).  WEIGHTS = 1 adds the kernels'
+// weight stream: 4 x 16 bytes per lane per tap from an L2-resident blob, requested one tap ahead (current/next register pair).
 // Build/run: hipcc --offload-arch=gfx950 -O3 tools/probes/mfma_lds_probe.hip -o /tmp/p && /tmp/p
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -8,8 +9,8 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-template <int READS, int DEPTH>
-__global__ void probe(float* out, int iters) {
+template <int READS, int DEPTH, int WEIGHTS>
+__global__ void probe(float* out, int iters, const uint4* wblob) {
   __shared__ uint4 lds[2 * 2496];  // one halo-tile buffer, hi | lo, as in conv_kernel
   unsigned h = threadIdx.x * 2654435761u + 12345u;
   for (int i = threadIdx.x; i < 2 * 2496; i += blockDim.x) {
@@ -35,6 +36,10 @@ __global__ void probe(float* out, int iters) {
   for (int i = 0; i < 8; ++i)
     for (int c = 0; c < 2; ++c) acc[i][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
   constexpr int NSTEP = 72;  // 9 taps x 8 pixel tiles
+  const uint4* wp = wblob + (threadIdx.x & 63);
+  uint4 wnx[4];
+  if (WEIGHTS)
+    for (int k = 0; k < 4; ++k) wnx[k] = wp[k * 64];
   for (int it = 0; it < iters; ++it) {
     bf16x8 rh[DEPTH + 1], rl[DEPTH + 1];
     auto unit = [&](int i) { const int t = i / 8, pt = i % 8; return base + ((pt >> 1) + t / 3) * 34 + (pt & 1) * 16 + t % 3; };
@@ -58,6 +63,16 @@ __global__ void probe(float* out, int iters) {
         rl[(i + DEPTH) % (DEPTH + 1)] = *(const bf16x8*)&lds[2496 + unit(i + DEPTH)];
       }
       const int sp = i % 8;
+      if (WEIGHTS && sp == 0) {
+        wh[0] = __builtin_bit_cast(bf16x8, wnx[0]);
+        wl[0] = __builtin_bit_cast(bf16x8, wnx[1]);
+        wh[1] = __builtin_bit_cast(bf16x8, wnx[2]);
+        wl[1] = __builtin_bit_cast(bf16x8, wnx[3]);
+        const int s = ((it * 9 + i / 8 + 1) % 45) * 256;  // 45 steps x 4 KB, as a 160-channel layer
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wnx[k] = wp[s + k * 64];
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
@@ -80,31 +95,35 @@ __global__ void probe(float* out, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
-template <int READS, int DEPTH>
-static void run(int waves_per_simd, float* out) {
+template <int READS, int DEPTH, int WEIGHTS>
+static void run(int waves_per_simd, float* out, const uint4* wblob) {
   const int iters = 2000, threads = 256 * waves_per_simd, blocks = 256;
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  probe<READS, DEPTH><<<blocks, threads>>>(out, 10);
+  probe<READS, DEPTH, WEIGHTS><<<blocks, threads>>>(out, 10, wblob);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  probe<READS, DEPTH><<<blocks, threads>>>(out, iters);
+  probe<READS, DEPTH, WEIGHTS><<<blocks, threads>>>(out, iters, wblob);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0;
   hipEventElapsedTime(&ms, e0, e1);
   const double flop = 2.0 * 16 * 16 * 32 * 432.0 * iters * (threads / 64) * blocks;
-  printf("waves/SIMD %d, LDS reads %s, depth %d: %8.3f ms  %7.1f TFLOP/s issued\n", waves_per_simd, READS ? "yes" : "no ", DEPTH, ms, flop / ms / 1e9);
+  printf("waves/SIMD %d, LDS reads %s, depth %d, weight stream %s: %8.3f ms  %7.1f TFLOP/s issued\n", waves_per_simd, READS ? "yes" : "no ", DEPTH, WEIGHTS ? "yes" : "no ", ms, flop / ms / 1e9);
 }
 
 int main() {
   float* out;
   hipMalloc(&out, 256 * 1024 * sizeof(float));
+  uint4* wblob;
+  hipMalloc(&wblob, 46 * 256 * sizeof(uint4) + 4096);
+  hipMemset(wblob, 0x3c, 46 * 256 * sizeof(uint4) + 4096);  // bf16 0x3c3c = 0.0115
   for (int w = 1; w <= 2; ++w) {
-    run<0, 2>(w, out);
-    run<1, 2>(w, out);
-    run<1, 4>(w, out);
+    run<0, 2, 0>(w, out, wblob);
+    run<1, 2, 0>(w, out, wblob);
+    run<1, 4, 0>(w, out, wblob);
+    run<1, 2, 1>(w, out, wblob);
   }
   return 0;
 }
