@@ -5,11 +5,17 @@ Contract (see the task statement): ``python bench.py --gpus N --steps K --warmup
 A *step* is one full forward pass of the hot path over one synthetic 3x1080x1920 frame per GPU
 (1920x1080 -> 7680x4320 = 33.18 output MP), input resident in HBM before the timed region, output left in HBM.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): tile-parallel inference (resselt_amd/tiling.py) of ONE
-image made of N 1080p tiles (grid chosen by choose_grid: 1x2, 2x2, 2x4): every rank upsamples its own tile plus a
-32-pixel input halo (weak scaling; no activation exchange -- the path shards by independent tiles) and
-the upscaled tiles are reassembled on every rank by an RCCL all-gather over xGMI, which is inside the timed region.
-``value`` = output MP of the whole image / max-over-ranks time.
+N > 1, one rank per GPU.  Under ``torch.distributed.run`` (WORLD_SIZE set) this process IS a rank; otherwise the process is
+the launcher: before it touches the GPU it starts ``python -m torch.distributed.run --nproc-per-node N bench.py ...`` as a
+child, relays rank 0's JSON line and exits with the child's status.
+
+  --config c2 (default, ``"scaling": "weak"``): tile-parallel inference (resselt_amd/tiling.py) of ONE image made of N 1080p
+      tiles (grid 1x2, 2x2, 2x4 = the 16:9 tile aspect): every rank upsamples its own tile plus a 32-pixel input halo and the
+      upscaled tiles are reassembled on every rank by an RCCL all-gather over xGMI, inside the timed region.
+  --config c5 (``"scaling": "strong"``): BASELINE.json configs[4] -- one 3x4320x7680 input cut into 2x4 tiles of 2160x1920
+      (+halo 32) dealt round-robin to the N ranks (N divides 8); a rank runs each of its tiles in 1080p-sized sub-tiles
+      so that its activation buffers stay those of the 1080p plan.
+``value`` = output MP of the whole image / max-over-ranks time, in both modes.
 
 Extra objects on the JSON line:
   roofline      dominant kernel (the fused conv kernel family = every launch of the forward), MFMA-bound:
@@ -51,53 +57,155 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-crop', type=int, default=256)
     ap.add_argument('--halo', type=int, default=32)
+    ap.add_argument('--config', default='c2', choices=['c2', 'c5'], help='c2: N tiles of 1080p (weak scaling); c5: one 4320x7680 input, 2x4 tiles (strong scaling)')
     return ap.parse_args()
 
 
+def launch_ranks(n: int) -> int:
+    """``python bench.py --gpus N`` without torch.distributed.run: start the N ranks as a child job.  Nothing in this process has
+    initialised the GPU (importing torch does not), and no exec happens: the parent waits and relays rank 0's JSON line."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__), *sys.argv[1:]]  # fmt: skip
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f'bench.py: the {n}-rank child job failed (status {proc.returncode})', file=sys.stderr)
+        return proc.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
 def cpu_baseline(sd, crop: int) -> dict:
-    """Time the CPU oracle on a bounded crop of the same workload (reported baseline, not a target)."""
+    """Time the CPU oracle on a bounded crop of the same workload (reported baseline, not a target): at 8 threads (the survey's
+    setting) and at the host's physical core count; ``value`` is the faster of the two, both are listed."""
     from oracle.rrdbnet import rrdbnet_forward
     from resselt_amd.utils import synth
 
+    try:
+        import psutil
+
+        phys = psutil.cpu_count(logical=False) or os.cpu_count() or 8
+    except Exception:
+        phys = os.cpu_count() or 8
     x = synth.synth_input((1, 3, crop, crop), seed=0)
-    threads = torch.get_num_threads()
-    best = None
-    with torch.no_grad():
-        for _ in range(2):
-            t0 = time.perf_counter()
-            y = rrdbnet_forward(sd, x)
-            dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
-    out_mp = y.shape[-1] * y.shape[-2] / 1e6
+    runs = {}
+    default_threads = torch.get_num_threads()
+    for threads in sorted({8, phys}):
+        torch.set_num_threads(threads)
+        best = None
+        with torch.no_grad():
+            for _ in range(2):
+                t0 = time.perf_counter()
+                y = rrdbnet_forward(sd, x)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+        runs[threads] = (y.shape[-1] * y.shape[-2] / 1e6 / best, best)
+    torch.set_num_threads(default_threads)
+    cores = max(runs, key=lambda k: runs[k][0])
     return {
-        'value': round(out_mp / best, 4),
+        'value': round(runs[cores][0], 4),
         'unit': 'output megapixels/s',
-        'cores': threads,
+        'cores': cores,
         'kind': 'port',
-        'sample': f'oracle/rrdbnet.py fp32 on one 3x{crop}x{crop} crop of the synthetic frame (best of 2, {best:.2f} s), torch {torch.__version__} CPU',
+        'sample': f'oracle/rrdbnet.py fp32 on one 3x{crop}x{crop} crop of the synthetic frame (best of 2 per thread count), torch {torch.__version__} CPU',
+        'by_threads': {str(k): {'value': round(v[0], 4), 'seconds': round(v[1], 2)} for k, v in runs.items()},
+        'host_physical_cores': phys,
     }
 
 
-def measured_traffic():
-    """HBM bytes per conv launch from the committed rocprofv3 PMC summary (tools/hbm_traffic.py; separate FETCH_SIZE / WRITE_SIZE
-    passes of this same command, gfx950 x2 FETCH correction).  Counters cannot be read from inside the timed process."""
+def measured_traffic() -> dict:
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (tools/hbm_traffic.py: separate FETCH_SIZE /
+    WRITE_SIZE passes of this same command, gfx950 x2 FETCH correction).  Counters cannot be read from inside the timed process, so the
+    summary carries the source hash of the library it was collected on; when that differs from the library loaded now the number is
+    stale and ``traffic`` is reported as null."""
     import glob
+
+    from resselt_amd import build as B
 
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_hbm_traffic.json')))
     if not files:
-        return None, None
+        return {'bytes': None, 'note': 'no PMC summary under profiles/'}
     rec = json.load(open(files[-1]))
-    return rec.get('traffic_GB_per_launch', 0) * 1e9, os.path.basename(files[-1])
+    name = os.path.basename(files[-1])
+    have = open(B.STAMP).read().strip() if os.path.exists(B.STAMP) else None
+    if rec.get('srchash') is None or rec.get('srchash') != have:
+        return {'bytes': None, 'note': f'{name} was collected on another build (srchash {str(rec.get("srchash"))[:12]} != loaded {str(have)[:12]}): stale, not reported'}
+    dom = rec.get('dominant', {})
+    return {'bytes': dom.get('traffic_bytes_per_launch'), 'note': f'{name}: {dom.get("kernel")}, FETCH_SIZE x2 + WRITE_SIZE per launch; whole forward '
+            f'{rec.get("traffic_GB_per_forward", 0):.1f} GB = {rec.get("traffic_over_algorithmic", 0):.2f}x the 258.5 GB layer-wise bf16 model'}  # fmt: skip
+
+
+def kernel_classes(model, reps: int) -> list:
+    """Per-kernel roofline, measured live: every launch descriptor of the model's 1080p plan is replayed alone through the C-ABI
+    between two HIP events on the launch stream (``reps`` launches per distinct layer shape), grouped by the kernel it dispatches to."""
+    from resselt_amd.engine import lib as L
+
+    plan = model.last_plan()
+    stream = torch.cuda.current_stream().cuda_stream
+    shapes: dict = {}
+    for arr in plan.conv_arrays:
+        for i in range(len(arr)):
+            p = arr[i]
+            key = (p.ksize, p.cin_planes, p.cout, p.H, p.W, p.upsample2x, bool(p.out_nchw), p.products)
+            shapes.setdefault(key, [0, arr, i])[0] += 1
+    groups: dict = {}
+    for key, (count, arr, i) in shapes.items():
+        one = (L.ConvParams * 1)(arr[i])
+        L.conv2d_list(one, stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            L.conv2d_list(one, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        ks, cin_planes, cout, h, w, up, final, prod = key
+        flop = 2.0 * ks * ks * cin_planes * 8 * cout * h * w * arr[i].batch
+        name = L.conv_kernel_name(arr[i])
+        g = groups.setdefault(name, {'kernel': name, 'launches': 0, 'us': 0.0, 'flop': 0.0})
+        g['launches'] += count
+        g['us'] += count * us
+        g['flop'] += count * flop
+    out = []
+    for g in groups.values():
+        out.append({
+            'kernel': g['kernel'],
+            'launches': g['launches'],
+            'avg_us': round(g['us'] / g['launches'], 2),
+            'ms_per_forward': round(g['us'] / 1e3, 3),
+            'flop_per_launch': round(g['flop'] / g['launches']),
+            'tflops': round(g['flop'] / g['us'] / 1e6, 2),
+        })  # fmt: skip
+    return sorted(out, key=lambda c: -c['ms_per_forward'])
 
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
+        raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE={world} of the launcher')
+    if args.config == 'c5' and 8 % world:
+        raise SystemExit('--config c5 has 8 tiles: --gpus must divide 8')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the engine has no CPU path')
     # RSA_DIST_BACKEND=gloo rehearses the N > 1 code path with several ranks on ONE GPU (RCCL refuses two ranks per device)
@@ -121,12 +229,25 @@ def main():
     model = resselt_amd.load_from_state_dict(dict(sd)).to(dev)
     model.precision = args.precision
     H, W = args.height, args.width
-    from resselt_amd.tiling import TileParallel, choose_grid
+    from resselt_amd.tiling import TileParallel, choose_grid, upscale_tiled
 
-    rows, cols = choose_grid(world, world * H, W) if world > 1 else (1, 1)
-    # the same full input image on every rank (3 channels: cheap to replicate); each rank owns one HxW tile of it
-    x = synth.synth_input((1, 3, rows * H, cols * W), seed=0).to(dev)
-    runner = TileParallel(model, scale=4, halo=args.halo, grid=(rows, cols)) if world > 1 else model
+    if args.config == 'c5':
+        # BASELINE.json configs[4]: one 4320x7680 input, 2x4 tiles of 2160x1920 dealt round-robin to the ranks; each rank runs a tile
+        # (2160x1920 + halo) as 1080p-sized sub-tiles, so its buffers are those of the 1080p plan (strong scaling: total work is fixed)
+        rows, cols = 2, 4
+        img_h, img_w = 4 * H, 4 * W
+        assert (img_h, img_w) == (rows * 2 * H, cols * W)
+        inner = lambda crop: upscale_tiled(model, crop, 4, tile=(H + 2 * args.halo, W + 2 * args.halo), halo=args.halo)  # noqa: E731
+        runner = TileParallel(inner, scale=4, halo=args.halo, grid=(rows, cols))
+    else:
+        # N tiles of HxW (weak scaling): 1x2, 2x2, 2x4 for N = 2, 4, 8 -- the grid that keeps the 16:9 tile aspect
+        rows, cols = choose_grid(world, H, W) if world > 1 else (1, 1)
+        img_h, img_w = rows * H, cols * W
+        if world == 8:
+            assert (rows, cols) == (2, 4) and (img_h, img_w) == (2 * H, 4 * W)
+        runner = TileParallel(model, scale=4, halo=args.halo, grid=(rows, cols)) if world > 1 else model
+    # the same full input image on every rank (3 channels: cheap to replicate); each rank owns its tile(s) of it
+    x = synth.synth_input((1, 3, img_h, img_w), seed=0).to(dev)
 
     def step():
         return runner(x)  # N > 1: tile forward + RCCL all-gather; every rank ends with the whole upscaled image
@@ -158,12 +279,13 @@ def main():
         dt = float(t.item())
 
     total_out_px = y.shape[-1] * y.shape[-2] * y.shape[0]  # whole image (on every rank after the all-gather)
-    out_px = total_out_px // world  # one tile
+    assert total_out_px == 16 * img_h * img_w
     ms_per_step = dt / args.steps * 1e3
     value = total_out_px / 1e6 / (dt / args.steps)
+    del y
 
     if rank == 0:
-        # kernel-only time of the conv launches of one forward, from HIP events on the launch stream
+        # kernel-only time of the conv launches of one forward of ONE HxW frame, from HIP events on the launch stream
         k0 = torch.cuda.Event(enable_timing=True)
         k1 = torch.cuda.Event(enable_timing=True)
         xt = x[:, :, :H, :W].contiguous()
@@ -175,6 +297,7 @@ def main():
         k1.record()
         torch.cuda.synchronize()
         kern_s = k0.elapsed_time(k1) / 1e3 / args.steps
+        out_px = 16 * H * W
         n_launch = model.launches_per_forward()
         macs = model.macs_per_input_pixel()
         if args.blocks == 23:
@@ -183,7 +306,15 @@ def main():
         achieved_tf = flop / kern_s / 1e12
         achieved_gbs = HBM_B_PER_OUT_PX * out_px / kern_s / 1e9
         layout_bytes = model.conv_bytes_per_forward()  # same layer-wise model, priced in this engine's split-plane/f32-map layouts
-        traffic, traffic_src = measured_traffic() if (args.precision == 'bf16x3' and (H, W, args.blocks) == (1080, 1920, 23)) else (None, None)
+        nprod = 3 if args.precision == 'bf16x3' else 1
+        classes = kernel_classes(model, max(2, min(args.steps, 5)))
+        dom = max(classes, key=lambda c: c['ms_per_forward'])
+        traffic = measured_traffic() if (args.precision == 'bf16x3' and (H, W, args.blocks) == (1080, 1920, 23)) else {'bytes': None, 'note': 'PMC traffic is only collected for the default workload'}
+        tile_note = {
+            'c2': f'{rows}x{cols} tiles of {H}x{W} (+{args.halo} px input halo), one per GPU, RCCL all-gather of fp32 output tiles' if world > 1 else 'single tile',
+            'c5': f'one 3x{img_h}x{img_w} input, 2x4 tiles of {2 * H}x{W} (+{args.halo} px halo) dealt round-robin to {world} rank(s), each run as 1080p-sized sub-tiles; '
+            + ('RCCL all-gather of fp32 output tiles' if world > 1 else 'no collective'),
+        }[args.config]
         res = {
             'metric': 'output megapixels/sec, RealESRGAN-x4plus 1080p\u21924K, 1/2/4/8 MI355X',
             'value': round(value, 3),
@@ -193,29 +324,44 @@ def main():
             'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': 'strong' if args.config == 'c5' else 'weak',
             'vs_baseline': None,
             'dtype': 'bf16',
             'data': 'synthetic',
             'config': {
-                'workload': f'RealESRGAN-x4plus (RRDBNet nf64 nb{args.blocks} gc32 x4), 1x3x{H}x{W} fp32 frame per GPU -> 1x3x{4 * H}x{4 * W}, '
-                + ('bf16 MFMA operands split hi+lo (3 products), f32 accumulate/residual' if args.precision == 'bf16x3' else 'plain bf16 MFMA operands, f32 accumulate/residual')
+                'workload': (f'RealESRGAN-x4plus (RRDBNet nf64 nb{args.blocks} gc32 x4), 1x3x{H}x{W} fp32 frame per GPU -> 1x3x{4 * H}x{4 * W}, ' if args.config == 'c2' else
+                             f'RealESRGAN-x4plus (RRDBNet nf64 nb{args.blocks} gc32 x4), ONE 1x3x{img_h}x{img_w} fp32 image -> 1x3x{4 * img_h}x{4 * img_w} over all GPUs (BASELINE configs[4]), ')
+                + ('bf16 MFMA operands split hi+lo (3 products), f32 accumulate' if args.precision == 'bf16x3' else 'plain bf16 MFMA operands, f32 accumulate')
                 + ', synthetic uniform(+-1/sqrt(fan_in)) weights',
                 'precision': args.precision,
-                'tile_parallel': f'{rows}x{cols} tiles of {H}x{W} (+{args.halo} px input halo), one per GPU, RCCL all-gather of fp32 output tiles' if world > 1 else 'single tile',
+                'tile_parallel': tile_note,
                 'launches_per_step': n_launch,
             },
+            # the DOMINANT kernel (largest share of the frame), timed live per launch with HIP events on the launch stream
             'roofline': {
+                'bound': 'mfma',
+                'kernel': dom['kernel'],
+                'achieved': dom['tflops'],
+                'peak': MFMA_PEAK_TFLOPS,
+                'unit': 'TFLOP/s',
+                'frac': round(dom['tflops'] / MFMA_PEAK_TFLOPS, 4),
+                'traffic': traffic['bytes'],
+                'traffic_note': traffic['note'],
+                'avg_launch_us': dom['avg_us'],
+                'launches_per_forward': dom['launches'],
+                'flop_per_launch': dom['flop_per_launch'],
+                'mfma_issued_frac': round(dom['tflops'] * nprod / MFMA_PEAK_TFLOPS, 4),
+                'share_of_frame': round(dom['ms_per_forward'] / (kern_s * 1e3), 3),
+            },
+            'roofline_kernels': classes,  # every kernel class of the forward, same definitions
+            'roofline_frame': {
                 'bound': 'mfma',
                 'achieved': round(achieved_tf, 2),
                 'peak': MFMA_PEAK_TFLOPS,
                 'unit': 'TFLOP/s',
                 'frac': round(achieved_tf / MFMA_PEAK_TFLOPS, 4),
-                'traffic': traffic,
-                'traffic_unit': 'HBM bytes per launch (avg over the 351 conv launches), from ' + traffic_src if traffic else None,
-                'kernel': 'rsa::conv_kernel<KS,NCT,PROD,UP,OUTK> (all 351 conv launches of one forward)',
-                'avg_launch_us': None if not n_launch else round(kern_s / n_launch * 1e6, 2),
-                'mfma_issued_frac': round(achieved_tf * (3 if args.precision == 'bf16x3' else 1) / MFMA_PEAK_TFLOPS, 4),
+                'mfma_issued_frac': round(achieved_tf * nprod / MFMA_PEAK_TFLOPS, 4),
+                'note': f'all {n_launch} launches of one forward: 2,240,856 algorithmic FLOP per output pixel / event time of the forward',
             },
             'roofline_hbm': {
                 'bound': 'hbm',
@@ -226,10 +372,10 @@ def main():
                 'model': 'layer-wise bf16 bytes, 7,790 B per output pixel (SURVEY.md 8d)',
                 'layout_bytes_per_launch': None if not layout_bytes else round(layout_bytes / n_launch),
                 'layout_achieved': None if not layout_bytes else round(layout_bytes / kern_s / 1e9, 1),
-                'layout_note': 'the same every-operand-once model priced in the engine layouts (hi+lo bf16 planes = 4 B/channel for 3 products, f32 residual maps); '
-                'compare roofline.traffic against layout_bytes_per_launch',
+                'layout_note': 'the same every-operand-once model priced in the engine layouts (hi+lo bf16 planes = 4 B/channel for 3 products)',
             },
             'event_ms_per_step': round(ev_ms / args.steps, 3),
+            'forward_ms_1080p': round(kern_s * 1e3, 3),
         }
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(sd, args.cpu_crop)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RSA_VERSION 100 /* 0.1.0 */
+#define RSA_VERSION 200 /* 0.2.0: rsa_conv_params.w_layout, rsa_pack_weights, ring schedule */
 
 /* error codes (negative = argument errors) */
 #define RSA_OK 0
@@ -119,6 +119,7 @@ typedef struct rsa_conv_params {
                                (Y, X) receives base pixel (min(Y / div, h-1), min(X / div, w-1)) -- F.interpolate(x, scale_factor=div) of the
                                UNPADDED input under a padded / unshuffled convolution grid (rtmosr/arch.py:383-387) */
   int32_t out_base_h, out_base_w;
+  int32_t w_layout;         /* layout of w_packed: must equal rsa_conv_weight_layout(this descriptor); see rsa_pack_weights */
 } rsa_conv_params;
 
 /* Launch `n` fused convolutions in order on `stream` (one host call per forward pass). */
@@ -133,11 +134,27 @@ int64_t rsa_packed_weight_bytes(int32_t cout, int32_t cin_planes, int32_t ksize,
 int rsa_conv_cout_tiles(int32_t cout);
 
 /*
- * Weight packing happens on the host side of the boundary (resselt_amd/engine/pack.py,
- * torch tensor ops, at load_state_dict time — reference registry.py:113); the blob layout is
- *   [cout_slab][chunk q][tap t][cout_tile][hi|lo][lane 0..63][8] bf16
- * with, for lane l: cout = 16*tile + (l & 15), cin = 32*q + 8*(l >> 4) + j   (DESIGN.md §3).
+ * Weight packing: OIHW f32 weights (device pointer, contiguous [cout][cin][k][k]) -> the MFMA A-fragment blob of
+ * rsa_packed_weight_bytes(cout, cin_planes, ksize, products) bytes that rsa_conv2d streams.  Replaces what
+ * nn.Module.load_state_dict does with an nn.Conv2d / nn.Linear weight (reference registry.py:113).  Two K orders exist and the
+ * schedule a descriptor dispatches to fixes which one it reads; ask with rsa_conv_weight_layout(descriptor) (every field except
+ * w_packed / w_layout filled in) and pass the answer as `layout` here and as rsa_conv_params.w_layout:
+ *   0  blob[chunk q][tap t][cout_tile][hi|lo][lane 0..63][8] bf16, lane l: cout = 16*tile + (l & 15), cin = 32*q + 8*(l >> 4) + j
+ *   1  tap-pair order of the ring schedule (3x3, three products, whole 32-channel chunks): resselt_amd/csrc/pack.hip
+ * (hi = bf16 RNE of w, lo = bf16 of w - hi; only hi when products == 1).
  */
+int rsa_conv_weight_layout(const rsa_conv_params* p);
+int rsa_pack_weights(const float* w_oihw, int32_t cout, int32_t cin, int32_t cin_planes, int32_t ksize, int32_t products, int32_t layout,
+                     void* out, void* stream);
+
+/* Name of the kernel a descriptor dispatches to (matches the rocprofv3 kernel names; bench.py groups its rooflines by it). */
+const char* rsa_conv_kernel_name(const rsa_conv_params* p);
+
+/* Debug: spins of the ring schedule's LDS hand-offs that ran into their bound (always 0 in a correct build; tests assert it). */
+int rsa_debug_ring_aborts(void);
+/* Debug: force the ring schedule on (1) / off (0) for descriptors built afterwards, or follow RSA_CONV_RING again (-1).  Descriptors carry
+ * the layout they were built for, so change it only between building descriptor sets (in-process A/B timing). */
+int rsa_debug_set_ring(int32_t mode);
 
 /*
  * Plain NCHW tensor [N][C][src_h][src_w] -> split planes of size H x W, with per-channel affine v = (x - mean[c]) * scale.

@@ -166,6 +166,20 @@ int rsa_conv2d_list(const rsa_conv_params* list, int32_t n, void* stream) {
 
 int rsa_conv_cout_tiles(int32_t cout) { return rsa::conv_nct(cout); }
 
+int rsa_conv_weight_layout(const rsa_conv_params* p) {
+  if (p == nullptr) return rsa::set_error(RSA_E_ARG, "rsa_conv_weight_layout: null params");
+  return rsa::conv_weight_layout(*p);
+}
+
+const char* rsa_conv_kernel_name(const rsa_conv_params* p) { return p == nullptr ? "" : rsa::conv_kernel_name(*p); }
+
+int rsa_debug_ring_aborts(void) { return (int)rsa::conv_ring_aborts(); }
+
+int rsa_debug_set_ring(int32_t mode) {
+  rsa::conv_ring_override(mode);
+  return RSA_OK;
+}
+
 int64_t rsa_packed_weight_bytes(int32_t cout, int32_t cin_planes, int32_t ksize, int32_t products) {
   if (cout < 1 || cin_planes < 1 || (ksize != 1 && ksize != 3) || (products != 1 && products != 3)) return RSA_E_ARG;
   const int64_t ct = (cout + 15) / 16;

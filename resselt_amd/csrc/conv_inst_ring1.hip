@@ -1,0 +1,25 @@
+// conv_inst_ring1.hip — conv_ring<STREAMS = 1> (49..64 output channels) and the dispatch of the ring schedule.
+#include "conv_ring.h"
+
+namespace rsa {
+int conv_launch_ring2(const rsa_conv_params& p, hipStream_t stream);  // conv_inst_ring2.hip
+
+int conv_launch_ring(const rsa_conv_params& p, hipStream_t stream) {
+  if (((p.cout + 15) >> 4) == 2) return conv_launch_ring2(p, stream);
+  return p.upsample2x ? launch_ring<1, 1, 0>(p, stream) : launch_ring<1, 0, 0>(p, stream);
+}
+
+unsigned int conv_ring_aborts() {
+  unsigned int v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ring_aborts), sizeof(v)) != hipSuccess) return 0xFFFFFFFFu;
+  return v;
+}
+}  // namespace rsa
+
+#ifdef RSA_RING_DEBUG
+namespace rsa { int conv_ring2_set_dbg(unsigned v); }
+extern "C" int rsa_debug_ring_flags(unsigned v) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(rsa::g_ring_dbg), &v, sizeof(v)) != hipSuccess) return -1;
+  return rsa::conv_ring2_set_dbg(v);
+}
+#endif

@@ -2,6 +2,9 @@
 // conv_inst_*.hip; wide 1x1 layers: gemm_k1.hip).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <atomic>
 
 #include "common.h"
 #include "resselt_amd.h"
@@ -15,6 +18,25 @@ int conv_launch_k3p1u0(const rsa_conv_params& p, int nct, hipStream_t stream);
 int conv_launch_k3p1u1(const rsa_conv_params& p, int nct, hipStream_t stream);
 int conv_launch_k1p3(const rsa_conv_params& p, int nct, hipStream_t stream);
 int conv_launch_k1p1(const rsa_conv_params& p, int nct, hipStream_t stream);
+
+static std::atomic<int> g_ring_override{-1};  // rsa_debug_set_ring: -1 = follow the environment, 0 / 1 = forced (in-process A/B runs)
+void conv_ring_override(int v) { g_ring_override.store(v < 0 ? -1 : (v ? 1 : 0)); }
+bool conv_ring_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("RSA_CONV_RING");
+    return e == nullptr || e[0] != '0';
+  }();
+  const int o = g_ring_override.load(std::memory_order_relaxed);
+  return o < 0 ? on : o != 0;
+}
+
+// Name of the kernel a descriptor dispatches to (bench.py groups its per-kernel roofline by it; matches the rocprofv3 kernel names).
+const char* conv_kernel_name(const rsa_conv_params& p) {
+  if (p.w_layout == RSA_WL_PAIRS) return ((p.cout + 15) >> 4) == 2 ? "rsa::conv_ring<2,UP,0> (Cout<=32)" : "rsa::conv_ring<1,UP,0> (Cout 49..64)";
+  if (p.ksize == 1 && p.cout >= 96 && p.out_nchw == nullptr) return "rsa::gemm_k1_kernel";
+  if (p.ksize == 3 && p.products == 3 && conv_nct(p.cout) == 2 && p.cout <= 32) return "rsa::conv_kernel_pp";
+  return p.out_nchw != nullptr ? "rsa::conv_kernel<..., OUTK=1> (final store)" : "rsa::conv_kernel";
+}
 
 int conv_nct(int cout) {
   const int ct = (cout + 15) / 16;
@@ -49,6 +71,14 @@ int conv_launch(const rsa_conv_params& p, hipStream_t stream) {
     const int ps = p.pixel_shuffle > 1 ? p.pixel_shuffle : 1;
     if (p.cout % (ps * ps) != 0) return set_error(RSA_E_ARG, "conv: cout not divisible by pixel_shuffle^2");
     if (p.out_dtype < RSA_F32 || p.out_dtype > RSA_BF16) return set_error(RSA_E_ARG, "conv: bad out_dtype");
+  }
+  if (p.w_layout != RSA_WL_TAPS && p.w_layout != RSA_WL_PAIRS) return set_error(RSA_E_ARG, "conv: unknown w_layout");
+  if (p.w_layout == RSA_WL_PAIRS) {  // ring schedule (conv_ring.h): the descriptor carries the K order its weights were packed in
+    if (!conv_ring_eligible(p))
+      return set_error(RSA_E_ARG, "conv: w_layout 1 (tap pairs) on a descriptor the ring schedule does not take (ask rsa_conv_weight_layout)");
+    if (p.in_plane_stride * 32 >= (int64_t)1 << 32) return set_error(RSA_E_UNSUPPORTED, "conv: input plane too large for 32-bit lane offsets; band the image");
+    const int rc = conv_launch_ring(p, stream);
+    return rc ? set_error(rc, "conv: ring kernel launch failed") : RSA_OK;
   }
   if (p.ksize == 1) {  // wide k1 layers (nn.Linear over tokens): weight-stationary GEMM schedule, gemm_k1.hip
     const int g = gemm_k1_launch(p, stream);

@@ -1,0 +1,406 @@
+// conv_ring.h — ring schedule of the fused 3x3 convolution (split-bf16, three products) for layers with whole 32-channel input
+// chunks and 17..32 or 49..64 output channels: every convolution of a residual dense block (utilities/block.py:454-465 of the
+// reference: 64/96/128/160 -> 32 and 192 -> 64), the trunk / upsampling / HR convolutions of RRDBNet (archs/esrgan/arch.py:82-118)
+// and any other 64-channel 3x3 layer (SRVGGNetCompact's body, archs/compact/arch.py:28-52).
+//
+// What it changes against conv_kernel.h / conv_kernel_pp.h (one workgroup barrier per 32-channel chunk, one halo fill in flight,
+// a fill has exactly one multiply phase to land):
+//
+//   * the halo tile is staged in HALF chunks of 16 channels (2 planes, hi + lo = 39 KB) through a ring of FOUR LDS slots, so a
+//     fill is in flight while the previous one is multiplied AND while the one before that is still being read;
+//   * no workgroup barrier in the steady state.  A slot has two LDS words: FULL (fills completed, written by the loader wave after
+//     a counted vmcnt) and FREE (releases, added to by each consumer wave after its last read).  Waves therefore drift: a wave that
+//     stores its tile (epilogue) does not hold up the wave it shares a SIMD with, and the loader keeps streaming across tile
+//     boundaries.  Every spin is bounded and ends the kernel through an abort word (g_ring_aborts counts them; tests assert 0);
+//   * one MFMA K step (32) = 16 channels x 2 taps (lane group lg: plane = lg & 1, tap = pair[lg >> 1]); nine K steps per 32
+//     channels as before: four tap pairs on half A, one step pairing tap (2,2) of half A with tap (2,2) of half B, four pairs on B.
+//     Bank-conflict free for the same reason as conv_kernel.h (the two lane groups of a ds_read_b128 slot group differ by a plane);
+//   * the loader's source addresses are (scalar tile base) + (per-lane constant): zero vector instructions per LDS-DMA on interior
+//     tiles (global_load_lds_dwordx4 v_off, s[base]); tiles that touch the image border take a per-lane path with the zero page;
+//   * tiles are ordered in bands of four tile rows, column-major inside a band, so that the 32 consecutive tiles an XCD works on at
+//     any time form a 4 x 8 block: the halo rows shared with the tile above / below are L2 hits instead of a second HBM fetch.
+//
+// Two shapes:  STREAMS == 2 (Cout <= 32): waves 0-3 / 4-7 are two independent streams, each with its own tiles, two ring slots
+// and loader wave (8 / 9); a wave owns 4 rows x 32 pixels x 2 cout tiles, so each activation fragment read from LDS feeds both
+// cout tiles.  STREAMS == 1 (Cout 49..64): eight waves = 2 cout groups x 4 row groups on one tile stream over all four slots.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "conv_common.h"
+#include "conv_kernel.h"
+
+#ifndef RSA_RING_SPIN_LIMIT
+#define RSA_RING_SPIN_LIMIT (1 << 18)
+#endif
+
+namespace rsa {
+
+#ifdef RSA_RING_DEBUG
+// experiment builds only (tools/variant.sh): runtime ablation mask, set through rsa_debug_ring_flags (not in the product library)
+//   1 = loader publishes without issuing DMA   2 = consumers skip the multiply (waits and releases stay)   4 = no weight loads
+//   8 = no epilogue   16 = no LDS fragment reads
+static __device__ unsigned int g_ring_dbg;
+#define RING_DBG(bit) (dbg & (bit))
+#else
+#define RING_DBG(bit) false
+#endif
+
+static __device__ unsigned int g_ring_aborts;  // spins that ran into RSA_RING_SPIN_LIMIT (a protocol bug): never non-zero in a correct build
+
+typedef const __attribute__((address_space(1))) char* gcptr;
+
+struct RingGeo {
+  static constexpr int TH = 16, TW = 32, IH = 18, IW = 34;
+  static constexpr int PS = 624;             // plane stride in units (IH*IW = 612 rounded up to 0 mod 16)
+  static constexpr int HALF = 2 * PS;        // units of one precision of a slot (2 planes)
+  static constexpr int SLOT = 2 * HALF;      // units per slot: [hi p0][hi p1][lo p0][lo p1]
+  static constexpr int NSLOT = 4;
+  static constexpr int DMA_IT = (HALF + 63) / 64;  // 20 LDS-DMA instructions per precision; the last one covers 32 units
+  static constexpr int BAND = 4;             // tile rows per band of the tile order
+};
+
+// tile index (band order) -> image, tile row, tile column
+__device__ __forceinline__ void ring_tile_coords(int t, int tiles_x, int tiles_y, int& n, int& ty, int& tx) {
+  const int tiles_img = tiles_x * tiles_y;
+  n = t / tiles_img;
+  const int r = t - n * tiles_img;
+  const int band = r / (RingGeo::BAND * tiles_x);
+  const int rr = r - band * RingGeo::BAND * tiles_x;
+  const int rows = min(RingGeo::BAND, tiles_y - band * RingGeo::BAND);
+  tx = rr / rows;
+  ty = band * RingGeo::BAND + (rr - tx * rows);
+}
+
+__device__ __forceinline__ uint32_t lds_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// Wait until *flag >= need.  The spin is bounded: when it runs out (a protocol bug), or a sibling wave's has, the abort word is
+// set and the wait returns anyway -- every later wait of the workgroup then returns after at most 64 polls, so the kernel always
+// drains (with wrong results, and g_ring_aborts != 0 to say so) instead of hanging the GPU.
+__device__ __forceinline__ void ring_wait_slow(const uint32_t* flag, uint32_t need, uint32_t* abort_word) {
+  for (int spin = 0; spin < RSA_RING_SPIN_LIMIT; ++spin) {
+    __builtin_amdgcn_s_sleep(1);
+    if (__builtin_amdgcn_readfirstlane(lds_ld(flag)) >= need) return;
+    if ((spin & 63) == 63 && __builtin_amdgcn_readfirstlane(lds_ld(abort_word)) != 0) return;
+  }
+  __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&g_ring_aborts, 1u);
+}
+__device__ __forceinline__ void ring_wait(const uint32_t* flag, uint32_t need, uint32_t* abort_word) {
+  if (__builtin_expect(__builtin_amdgcn_readfirstlane(lds_ld(flag)) < need, 0)) ring_wait_slow(flag, need, abort_word);
+}
+
+__device__ __forceinline__ gcptr uniform_ptr(gcptr q) {  // tell the compiler a pointer is wave-uniform (an SGPR pair)
+  const uint64_t v = (uint64_t)q;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (gcptr)(((uint64_t)hi << 32) | lo);
+}
+
+// LDS-DMA, 16 bytes per lane: LDS[m0 + lane*16] = *(saddr + voff)   /   = *vaddr
+__device__ __forceinline__ void dma16_s(uint32_t lds_addr, uint32_t voff, gcptr sbase) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void dma16_v(uint32_t lds_addr, gcptr vaddr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(vaddr) : "memory");
+}
+
+template <int STREAMS, int UP, int OUTK>
+__global__ __launch_bounds__((8 + STREAMS) * 64, 3) void conv_ring(const rsa_conv_params p) {
+  using R = RingGeo;
+  constexpr int TH = R::TH, TW = R::TW, IH = R::IH, IW = R::IW, PS = R::PS, HALF = R::HALF, SLOT = R::SLOT, NSLOT = R::NSLOT;
+  constexpr int NCT = (STREAMS == 2) ? 2 : 4;  // cout tiles of the layer handled by one workgroup
+  constexpr int CTW = 2, NPT = 8, RPW = 4;      // per wave: 2 cout tiles x 8 pixel tiles (4 rows x 2 halves)
+  constexpr int NCONS = (STREAMS == 2) ? 4 : 8; // consumer waves per slot
+  constexpr int SPS = NSLOT / STREAMS;          // slots per stream
+
+  // ring + flags in ONE shared array (a second __shared__ object can make hipcc drain vmcnt before LDS reads)
+  __shared__ uint4 s_ring[NSLOT * SLOT + 4];
+  uint32_t* const flags = (uint32_t*)&s_ring[NSLOT * SLOT];  // [0..3] FULL, [4..7] FREE, [8] abort
+  uint32_t* const f_full = flags;
+  uint32_t* const f_free = flags + 4;
+  uint32_t* const f_abort = flags + 8;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int tiles_x = (p.W + TW - 1) / TW;
+  const int tiles_y = (p.H + TH - 1) / TH;
+  const int num_tiles = tiles_x * tiles_y * p.batch;
+  const int nchunks = p.cin_planes >> 2;  // whole chunks only (checked by the launcher)
+  const int ct_total = (p.cout + 15) >> 4;
+
+  const int NWG = (int)gridDim.x;
+  const int tile0 = (NWG % 8 == 0) ? ((int)blockIdx.x % 8) * (NWG / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;  // XCD strips, as conv_kernel
+  if (tile0 >= num_tiles) return;  // whole workgroup
+  const int ntw = (num_tiles - tile0 + NWG - 1) / NWG;  // tiles of this workgroup: tile0 + j*NWG
+
+  if (tid < 16) flags[tid] = 0;
+  __syncthreads();  // the only workgroup barrier of the kernel
+#ifdef RSA_RING_DEBUG
+  const unsigned dbg = __builtin_amdgcn_readfirstlane(g_ring_dbg);
+#endif
+
+  if (wave >= 8) {
+    // =========================== LOADER WAVE (one per stream) ===========================
+    __builtin_amdgcn_s_setprio(3);
+    const int g = wave - 8;
+    const int inW = UP ? (p.W >> 1) : p.W;
+    // per-lane constants.  lc: byte offset of the unit each DMA instruction of this lane delivers, from the source unit of the
+    // tile's halo origin (halo row 0, column 0) in the half chunk's first plane -- never negative, so interior tiles address it as
+    // (scalar base) + (32-bit lane offset).  smap: the same unit as packed (plane, halo row, halo column) for the border path.
+    uint32_t lc[R::DMA_IT];
+    uint32_t smap[R::DMA_IT];
+#pragma unroll
+    for (int it = 0; it < R::DMA_IT; ++it) {
+      const int u = it * 64 + lane;
+      const int pl = (u / PS) & 1;
+      const int r = u % PS;
+      int py = r / IW, px = r - (r / IW) * IW;
+      if (r >= IH * IW) py = 0, px = 0;  // padding units of the plane stride: fetch the tile's first unit (never read by the multiply)
+      smap[it] = (uint32_t)(pl << 16 | py << 8 | px);
+      // UP: halo row py of a tile whose halo starts at output row y0 = 16*ty - 1 reads source row (y0 + py) >> 1 = (8*ty - 1) + ((py + 1) >> 1)
+      const int sy = UP ? ((py + 1) >> 1) : py;
+      const int sx = UP ? ((px + 1) >> 1) : px;
+      lc[it] = (uint32_t)(((int64_t)pl * p.in_plane_stride + (int64_t)sy * inW + sx) * 16);  // < 2^32: the launcher bounds the plane size
+    }
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)s_ring;
+    int k = 0;                      // half-chunk counter of this stream
+    int pend_slot = -1;             // fill issued but not yet published
+    uint32_t pend_val = 0;
+    for (int j = (STREAMS == 2 ? g : 0); j < ntw; j += STREAMS) {
+      int n, ty, tx;
+      ring_tile_coords(tile0 + j * NWG, tiles_x, tiles_y, n, ty, tx);
+      const int y0 = ty * TH - 1, x0 = tx * TW - 1;  // halo origin in OUTPUT coordinates
+      const bool interior = y0 >= 0 && x0 >= 0 && y0 + IH <= p.H && x0 + IW <= p.W;
+      // source unit of the halo origin in plane 0 of this image (used by interior tiles only, where it is inside the map)
+      const int64_t tile_unit = (int64_t)n * p.in_batch_stride + (int64_t)(UP ? ty * (TH / 2) - 1 : y0) * inW + (UP ? tx * (TW / 2) - 1 : x0);
+      for (int h = 0; h < 2 * nchunks; ++h, ++k) {
+        const int slot = (STREAMS == 2) ? 2 * g + (k & 1) : (k & 3);
+        const uint32_t use = (uint32_t)(k / SPS);  // how many times this slot has been filled before
+        // the slot must have been released by all its consumers `use` times
+        if (__builtin_amdgcn_readfirstlane(lds_ld(&f_free[slot])) < NCONS * use) {
+          if (pend_slot >= 0) {  // publish what has been issued before blocking: the consumers may need it to get here
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&f_full[pend_slot], pend_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            pend_slot = -1;
+          }
+          ring_wait(&f_free[slot], NCONS * use, f_abort);
+        }
+        const int64_t half_unit = tile_unit + (int64_t)(2 * h) * p.in_plane_stride;  // first plane of this half chunk
+        gcptr bh = uniform_ptr((gcptr)p.in_hi + half_unit * 16);
+        gcptr bl = uniform_ptr((gcptr)p.in_lo + half_unit * 16);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(ring_lds + (uint32_t)slot * (SLOT * 16));
+        if (RING_DBG(1)) {
+        } else if (interior) {
+#pragma unroll
+          for (int it = 0; it < R::DMA_IT; ++it) {
+            if (it == R::DMA_IT - 1 && lane >= 32) continue;  // the last instruction of a precision covers 32 units (EXEC-masked)
+            dma16_s(dst + it * 1024, lc[it], bh);
+            dma16_s(dst + HALF * 16 + it * 1024, lc[it], bl);
+          }
+        } else {
+#pragma unroll
+          for (int it = 0; it < R::DMA_IT; ++it) {
+            if (it == R::DMA_IT - 1 && lane >= 32) continue;
+            const uint32_t m = smap[it];
+            const int pl = (int)(m >> 16);
+            int iy = y0 + (int)((m >> 8) & 255u), ix = x0 + (int)(m & 255u);
+            const bool ok = (uint32_t)iy < (uint32_t)p.H && (uint32_t)ix < (uint32_t)p.W;
+            if (UP) {
+              iy >>= 1;
+              ix >>= 1;
+            }
+            const int64_t off = ((int64_t)n * p.in_batch_stride + (int64_t)(2 * h + pl) * p.in_plane_stride + (int64_t)iy * inW + ix) * 16;
+            gcptr sh = ok ? (gcptr)p.in_hi + off : (gcptr)&g_zero_unit[0];
+            gcptr sl = ok ? (gcptr)p.in_lo + off : (gcptr)&g_zero_unit[0];
+            dma16_v(dst + it * 1024, sh);
+            dma16_v(dst + HALF * 16 + it * 1024, sl);
+          }
+        }
+        if (pend_slot >= 0) {
+          // everything but the 2*DMA_IT instructions just issued has landed: publish the previous fill
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * R::DMA_IT) : "memory");
+          __hip_atomic_store(&f_full[pend_slot], pend_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        pend_slot = slot;
+        pend_val = use + 1;
+      }
+    }
+    if (pend_slot >= 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&f_full[pend_slot], pend_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return;
+  }
+
+  // =========================== COMPUTE WAVES ===========================
+  const int g = (STREAMS == 2) ? (wave >> 2) : 0;    // stream
+  const int wct = (STREAMS == 2) ? 0 : (wave >> 2);  // cout group (STREAMS == 1)
+  const int wpx = wave & 3;                          // group of 4 rows
+  const int li = lane & 15;
+  const int lg = lane >> 4;
+  const int hsel = lg >> 1;  // which tap of a pair / which half in the pairing step
+
+  // weights: per (chunk, K step 0..8, cout tile, hi|lo) one 1 KiB A fragment, streamed from L2 one K step ahead
+  const int nks = nchunks * 9;
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_packed, 0, (uint32_t)((int64_t)nks * ct_total * 2 * 64 * 16), 0x00020000);
+  uint32_t woff[CTW];
+#pragma unroll
+  for (int c = 0; c < CTW; ++c) {
+    const int ctg = wct * CTW + c;
+    woff[c] = (ctg < ct_total) ? (uint32_t)((ctg * 2 * 64 + lane) * 16) : 0xFFFFFFFFu;  // out of range -> zeros
+  }
+  const uint32_t wstep = (uint32_t)ct_total * 2 * 64 * 16;
+  bf16x8 wc[CTW][2], wn[CTW][2];
+  auto load_w = [&](int s) {
+#pragma unroll
+    for (int c = 0; c < CTW; ++c)
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl) {
+        if (RING_DBG(4)) continue;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, woff[c], (uint32_t)s * wstep + (uint32_t)hl * 1024u, 0);
+        wn[c][hl] = __builtin_bit_cast(bf16x8, v);
+      }
+  };
+
+  f32x4 acc[NPT][CTW];
+#pragma unroll
+  for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct) acc[pt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // per-lane fragment units (relative to the ring): lane (li, lg) reads plane lg & 1; pair steps read tap +hsel
+  //   uA1: half A, taps (dy, 0 | 1)      + dy*IW by immediate        uA2: half A, taps (0 | 1, 2)
+  //   uB1, uB2: the same for half B                                   uS : tap (2, 2) of half A (hsel 0) / half B (hsel 1)
+  const int lane_u = (lg & 1) * PS + (wpx * RPW) * IW + li;
+  const int slotA0 = (STREAMS == 2) ? 2 * g * SLOT : 0;
+  int uA1 = slotA0 + lane_u + hsel;
+  int uA2 = slotA0 + lane_u + 2 + hsel * IW;
+  int uB1 = uA1 + SLOT;
+  int uB2 = uA2 + SLOT;
+  int uS = slotA0 + lane_u + 2 * IW + 2 + hsel * SLOT;
+
+  load_w(0);
+  uint32_t cnt = 0;  // chunks this stream has consumed
+  for (int j = (STREAMS == 2 ? g : 0); j < ntw; j += STREAMS) {
+    for (int c = 0; c < nchunks; ++c, ++cnt) {
+      // slots of this chunk and how often each has been used before
+      const int sA = (STREAMS == 2) ? 2 * g : (int)(2 * (cnt & 1));
+      const int sB = sA + 1;
+      const uint32_t need = (STREAMS == 2) ? cnt + 1 : (cnt >> 1) + 1;
+      ring_wait(&f_full[sA], need, f_abort);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::: "memory");
+
+      constexpr int NSTEP = 72;  // 9 K steps x 8 pixel tiles
+      constexpr int DEPTH = 2;
+      bf16x8 rh[DEPTH + 1], rl[DEPTH + 1];
+      auto frag = [&](int i) -> int {  // unit of pixel-tile step i (compile-time i)
+        const int ks = i >> 3, pt = i & 7;
+        const int ptoff = (pt >> 1) * IW + (pt & 1) * 16;
+        switch (ks) {
+          case 0: return uA1 + ptoff;
+          case 1: return uA1 + IW + ptoff;
+          case 2: return uA1 + 2 * IW + ptoff;
+          case 3: return uA2 + ptoff;
+          case 4: return uS + ptoff;
+          case 5: return uB1 + ptoff;
+          case 6: return uB1 + IW + ptoff;
+          case 7: return uB1 + 2 * IW + ptoff;
+          default: return uB2 + ptoff;
+        }
+      };
+#pragma unroll
+      for (int i = 0; i < DEPTH; ++i) {
+        rh[i] = *(const bf16x8*)&s_ring[frag(i)];
+        rl[i] = *(const bf16x8*)&s_ring[HALF + frag(i)];
+      }
+      // one pixel-tile step: prefetch the fragments of step i + DEPTH, multiply step i (i is a compile-time constant after unrolling)
+      auto step = [&](int i) {
+        const int ks = i >> 3, sp = i & 7;
+        if (sp == 0) {
+#pragma unroll
+          for (int cc = 0; cc < CTW; ++cc)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) wc[cc][hl] = wn[cc][hl];
+          const int s = c * 9 + ks;
+          load_w(s + 1 < nks ? s + 1 : 0);  // next K step; after the last one: step 0 of the next tile
+          if (ks == 5) {
+            // every read of half A has been consumed by an MFMA (the last ones in step 39): hand the slot back to the loader
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&f_free[sA], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (i + DEPTH < NSTEP && !RING_DBG(16)) {
+          const int u = frag(i + DEPTH);
+          rh[(i + DEPTH) % (DEPTH + 1)] = *(const bf16x8*)&s_ring[u];
+          rl[(i + DEPTH) % (DEPTH + 1)] = *(const bf16x8*)&s_ring[HALF + u];
+        }
+        if (!RING_DBG(2))
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+          for (int ct = 0; ct < CTW; ++ct) {
+            // products in increasing magnitude: w_lo*a_hi, w_hi*a_lo, w_hi*a_hi
+            const bf16x8 wf = (pr == 0) ? wc[ct][1] : wc[ct][0];
+            const bf16x8 bf = (pr == 1) ? rl[i % (DEPTH + 1)] : rh[i % (DEPTH + 1)];
+            acc[sp][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, bf, acc[sp][ct], 0, 0, 0);
+          }
+        if (i + DEPTH < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * CTW, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      constexpr int FIRST_B = 32 - DEPTH;  // the step whose prefetch is the first read of half B
+#pragma unroll
+      for (int i = 0; i < FIRST_B; ++i) step(i);
+      ring_wait(&f_full[sB], need, f_abort);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = FIRST_B; i < NSTEP; ++i) step(i);
+      asm volatile("" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(&f_free[sB], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (STREAMS == 1) {  // the next chunk lives in the other pair of slots
+        const int d = (cnt & 1) ? -2 * SLOT : 2 * SLOT;
+        uA1 += d;
+        uA2 += d;
+        uB1 += d;
+        uB2 += d;
+        uS += d;
+      }
+    }
+    // ---- tile finished: epilogue (the loader is already streaming the next tile; the wave sharing this SIMD keeps multiplying) ----
+    {
+      int n, ty, tx;
+      ring_tile_coords(tile0 + j * NWG, tiles_x, tiles_y, n, ty, tx);
+      if (!RING_DBG(8)) epilogue<NCT, CTW, NPT, OUTK>(p, acc, n, ty * TH, tx * TW, 0, wct, wpx, li, lg);
+    }
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < CTW; ++ct) acc[pt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+template <int STREAMS, int UP, int OUTK>
+static int launch_ring(const rsa_conv_params& p, hipStream_t stream) {
+  using R = RingGeo;
+  const int tiles_x = (p.W + R::TW - 1) / R::TW;
+  const int tiles_y = (p.H + R::TH - 1) / R::TH;
+  const int64_t num_tiles = (int64_t)tiles_x * tiles_y * p.batch;
+  if (num_tiles > 0x3fffffff) return RSA_E_UNSUPPORTED;
+  static const int cus = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount;
+  }();
+  int gx = cus;  // one persistent workgroup per CU (the ring takes the whole LDS)
+  if (gx > num_tiles) gx = (int)num_tiles;
+  hipLaunchKernelGGL((conv_ring<STREAMS, UP, OUTK>), dim3((unsigned)gx, 1, 1), dim3((8 + STREAMS) * 64), 0, stream, p);
+  return (int)hipGetLastError();
+}
+
+}  // namespace rsa

@@ -1,0 +1,91 @@
+// pack.hip — rsa_pack_weights: OIHW f32 convolution weights -> the MFMA A-fragment blob the convolution kernels stream
+// (split bf16: hi = RNE(w), lo = RNE(w - hi)).  Replaces, on the device and behind the C-ABI, what nn.Module.load_state_dict
+// does for the reference's nn.Conv2d parameters (reference registry.py:113): the engine's kernels never see OIHW.
+//
+// One thread per (K step, cout tile, lane) writes that lane's 8-element fragment of hi (and lo).
+//   layout RSA_WL_TAPS  (conv_kernel.h, gemm_k1.hip): blob[q][t][ct][hl][lane][j], K step = (chunk q of 32 channels, tap t):
+//        cout = 16*ct + (lane & 15), cin = 32*q + 8*(lane >> 4) + j
+//   layout RSA_WL_PAIRS (conv_ring.h, 3x3 only): blob[q][s][ct][hl][lane][j], s = 0..8; lane group lg = lane >> 4 reads plane
+//        (lg & 1) of a 16-channel half (A = planes 4q, 4q+1; B = 4q+2, 4q+3) at one tap of the step's pair, selected by h = lg >> 1:
+//        s = 0,1,2: half A, tap (dy = s, dx = h)      s = 3: half A, tap (dy = h, dx = 2)      s = 4: tap (2,2) of half A (h = 0) / B (h = 1)
+//        s = 5,6,7: half B, tap (dy = s-5, dx = h)    s = 8: half B, tap (dy = h, dx = 2)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+#include "resselt_amd.h"
+
+namespace rsa {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 pk_bf16x8;
+
+__global__ void pack_weights_kernel(const float* __restrict__ w, int cout, int cin, int cin_planes, int ksize, int products, int layout, void* out) {
+  const int T = ksize * ksize;
+  const int ct_total = (cout + 15) >> 4;
+  const int nq = (cin_planes + 3) >> 2;
+  const int nhl = products == 3 ? 2 : 1;
+  const int64_t total = (int64_t)nq * T * ct_total * 64;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    int64_t r = idx >> 6;
+    const int ct = (int)(r % ct_total);
+    r /= ct_total;
+    const int s = (int)(r % T);
+    const int q = (int)(r / T);
+    const int lg = lane >> 4;
+    const int co = 16 * ct + (lane & 15);
+    int plane, ky, kx;
+    if (layout == RSA_WL_PAIRS) {
+      const int h = lg >> 1;
+      const int half = s < 4 ? 0 : (s == 4 ? h : 1);
+      plane = 4 * q + 2 * half + (lg & 1);
+      const int ss = s < 4 ? s : (s == 4 ? 4 : s - 5);
+      if (ss < 3) {
+        ky = ss;
+        kx = h;
+      } else if (ss == 3) {
+        ky = h;
+        kx = 2;
+      } else {
+        ky = 2;
+        kx = 2;
+      }
+    } else {
+      plane = 4 * q + lg;
+      ky = s / ksize;
+      kx = s - ky * ksize;
+    }
+    pk_bf16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ci = 8 * plane + j;
+      float v = 0.f;
+      if (co < cout && ci < cin && plane < cin_planes) v = w[(((int64_t)co * cin + ci) * ksize + ky) * ksize + kx];
+      const __bf16 hb = (__bf16)v;
+      hi[j] = hb;
+      lo[j] = (__bf16)(v - (float)hb);
+    }
+    const int64_t frag = (((int64_t)q * T + s) * ct_total + ct) * nhl;  // 1 KiB fragments
+    ((pk_bf16x8*)out)[frag * 64 + lane] = hi;
+    if (nhl == 2) ((pk_bf16x8*)out)[(frag + 1) * 64 + lane] = lo;
+  }
+}
+
+}  // namespace rsa
+
+extern "C" int rsa_pack_weights(const float* w_oihw, int32_t cout, int32_t cin, int32_t cin_planes, int32_t ksize, int32_t products, int32_t layout,
+                                void* out, void* stream) {
+  if (w_oihw == nullptr || out == nullptr || cout < 1 || cin < 1 || cin_planes < 1) return rsa::set_error(RSA_E_ARG, "pack_weights: bad argument");
+  if ((ksize != 1 && ksize != 3) || (products != 1 && products != 3)) return rsa::set_error(RSA_E_ARG, "pack_weights: ksize must be 1 or 3, products 1 or 3");
+  if (cin > 8 * cin_planes) return rsa::set_error(RSA_E_ARG, "pack_weights: cin does not fit in cin_planes");
+  if (layout != rsa::RSA_WL_TAPS && layout != rsa::RSA_WL_PAIRS) return rsa::set_error(RSA_E_ARG, "pack_weights: unknown layout");
+  if (layout == rsa::RSA_WL_PAIRS && (ksize != 3 || products != 3 || (cin_planes & 3))) return rsa::set_error(RSA_E_UNSUPPORTED, "pack_weights: the tap-pair layout needs a 3x3, 3-product layer with whole 32-channel chunks");
+  if ((uintptr_t)out & 15) return rsa::set_error(RSA_E_ALIGN, "pack_weights: out must be 16-byte aligned");
+  const int64_t total = (int64_t)((cin_planes + 3) / 4) * ksize * ksize * ((cout + 15) / 16) * 64;
+  int64_t grid = (total + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(rsa::pack_weights_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, cin_planes, ksize, products,
+                     layout, out);
+  const int rc = (int)hipGetLastError();
+  return rc ? rsa::set_error(rc, "pack_weights: launch failed") : RSA_OK;
+}

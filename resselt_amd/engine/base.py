@@ -45,6 +45,7 @@ class Plan:
         self.keep: list[object] = []  # tensors referenced by raw pointer in the descriptors
         self.steps: list[Callable[[], None]] = []  # executed in order on the current stream
         self._pending: list[L.ConvParams] = []
+        self.conv_arrays: list = []  # every flushed descriptor array, in launch order (bench.py replays single entries)
 
     # ---- buffers ----
     def planes(self, n, planes, h, w, with_lo=True) -> Planes:
@@ -70,6 +71,7 @@ class Plan:
         arr = (L.ConvParams * len(self._pending))(*self._pending)
         self._n_launches = getattr(self, '_n_launches', 0) + len(self._pending)
         self._pending = []
+        self.conv_arrays.append(arr)
         dev = self.device
         self.steps.append(lambda: L.conv2d_list(arr, ops.current_stream_ptr(dev)))
         return arr
@@ -141,6 +143,12 @@ class EngineModule(nn.Module):
         if not self._plans:
             return None
         return list(self._plans.values())[-1][0].n_launches()
+
+    def last_plan(self) -> 'Plan | None':
+        """The most recently built plan (None before the first forward)."""
+        if not self._plans:
+            return None
+        return list(self._plans.values())[-1][0]
 
     def conv_bytes_per_forward(self) -> int | None:
         if not self._plans:

@@ -60,6 +60,7 @@ class ConvParams(C.Structure):
         ('out_base_div', C.c_int32),
         ('out_base_h', C.c_int32),
         ('out_base_w', C.c_int32),
+        ('w_layout', C.c_int32),
     ]
 
 
@@ -298,6 +299,11 @@ EXPORTS = (
     'rsa_conv2d_list',
     'rsa_conv_cout_tiles',
     'rsa_packed_weight_bytes',
+    'rsa_conv_weight_layout',
+    'rsa_pack_weights',
+    'rsa_conv_kernel_name',
+    'rsa_debug_ring_aborts',
+    'rsa_debug_set_ring',
     'rsa_nchw_to_planes',
     'rsa_planes_to_nchw',
     'rsa_dysample',
@@ -350,6 +356,16 @@ def load() -> C.CDLL:
     lib.rsa_conv_cout_tiles.restype = C.c_int
     lib.rsa_packed_weight_bytes.argtypes = [C.c_int32] * 4
     lib.rsa_packed_weight_bytes.restype = C.c_int64
+    lib.rsa_conv_weight_layout.argtypes = [C.POINTER(ConvParams)]
+    lib.rsa_conv_weight_layout.restype = C.c_int
+    lib.rsa_pack_weights.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.rsa_pack_weights.restype = C.c_int
+    lib.rsa_conv_kernel_name.argtypes = [C.POINTER(ConvParams)]
+    lib.rsa_conv_kernel_name.restype = C.c_char_p
+    lib.rsa_debug_ring_aborts.argtypes = []
+    lib.rsa_debug_ring_aborts.restype = C.c_int
+    lib.rsa_debug_set_ring.argtypes = [C.c_int32]
+    lib.rsa_debug_set_ring.restype = C.c_int
     lib.rsa_nchw_to_planes.argtypes = [
         C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_float,
         C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
@@ -411,6 +427,14 @@ def conv2d_list(params: 'C.Array[ConvParams] | list[ConvParams]', stream: int) -
     else:
         arr = params
     check(lib.rsa_conv2d_list(arr, len(arr), C.c_void_p(stream)), 'rsa_conv2d_list')
+
+
+def conv_kernel_name(p: ConvParams) -> str:
+    return load().rsa_conv_kernel_name(C.byref(p)).decode()
+
+
+def ring_aborts() -> int:
+    return int(load().rsa_debug_ring_aborts())
 
 
 def cout_tiles(cout: int) -> int:

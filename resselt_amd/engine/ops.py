@@ -34,17 +34,36 @@ def require_cuda(x: torch.Tensor, what: str) -> None:
         )
 
 
+def pack_weights_device(w: torch.Tensor, cin_planes: int, products: int, layout: int) -> torch.Tensor:
+    """OIHW f32 weights on the GPU -> packed A-fragment blob (``rsa_pack_weights``, one kernel; csrc/pack.hip)."""
+    require_cuda(w, 'pack_weights')
+    w = w.to(torch.float32).contiguous()
+    cout, cin, k, _ = w.shape
+    lib = L.load()
+    nbytes = int(lib.rsa_packed_weight_bytes(cout, cin_planes, k, products))
+    if nbytes <= 0:
+        raise ValueError(f'unsupported convolution shape cout={cout} cin_planes={cin_planes} k={k} products={products}')
+    out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
+    with torch.cuda.device(w.device):
+        L.check(lib.rsa_pack_weights(w.data_ptr(), cout, cin, cin_planes, k, products, layout, out.data_ptr(), C.c_void_p(current_stream_ptr(w.device))),
+                'rsa_pack_weights')  # fmt: skip
+    return out
+
+
 @dataclass
 class ConvWeights:
-    """One convolution's device-resident, pre-packed parameters."""
+    """One convolution's device-resident parameters.  ``packed`` is the blob in layout 0 (tap-major K order), or None when the
+    weights are kept as f32 OIHW (``w``) and packed on demand in the layout the descriptor's schedule reads (``packed_for``)."""
 
-    packed: torch.Tensor  # bf16 blob, see pack.py
+    packed: torch.Tensor | None  # bf16 blob in layout 0, see pack.py / csrc/pack.hip
     bias: torch.Tensor  # f32, padded to 16
     cout: int
     cin: int
     cin_planes: int
     ksize: int
     products: int
+    w: torch.Tensor | None = None  # f32 OIHW source on the device
+    _by_layout: dict | None = None
 
     @staticmethod
     def from_oihw(w: torch.Tensor, b: torch.Tensor | None, products: int, cin_planes: int | None = None, device=None) -> 'ConvWeights':
@@ -52,9 +71,22 @@ class ConvWeights:
         cout, cin, k, _ = w.shape
         if cin_planes is None:
             cin_planes = (cin + 7) // 8
-        packed = pack_conv_weights(w.to(device=device, dtype=torch.float32), cin_planes, products)
+        if cin > 8 * cin_planes:
+            raise ValueError(f'cin={cin} does not fit in {cin_planes} planes')
         bias = pad_bias(None if b is None else b.to(device), cout, device)
-        return ConvWeights(packed, bias, cout, cin, cin_planes, k, products)
+        return ConvWeights(None, bias, cout, cin, cin_planes, k, products, w=w.detach().to(device=device, dtype=torch.float32).contiguous(), _by_layout={})
+
+    def packed_for(self, layout: int) -> torch.Tensor:
+        if self.w is None:  # a blob written directly by a kernel (e.g. rsa_channel_attention_weights): layout 0 only
+            if layout != 0:
+                raise ValueError('pre-packed weights exist in layout 0 only')
+            return self.packed
+        blob = self._by_layout.get(layout)
+        if blob is None:
+            blob = self._by_layout[layout] = pack_weights_device(self.w, self.cin_planes, self.products, layout)
+            if layout == 0:
+                self.packed = blob
+        return blob
 
 
 def conv_params(
@@ -105,7 +137,6 @@ def conv_params(
         raise ValueError('products=3 needs lo planes')
     p.in_plane_stride = x.plane_stride
     p.in_batch_stride = x.batch_stride
-    p.w_packed = wts.packed.data_ptr()
     p.bias = wts.bias.data_ptr()
     p.act = act
     p.act_param = act_param
@@ -149,6 +180,9 @@ def conv_params(
         if act_vec is None or act_vec.numel() < ((wts.cout + 15) // 16) * 16 or act_vec.dtype != torch.float32:
             raise ValueError('PReLU needs f32 slopes padded to a multiple of 16')
         p.act_vec = act_vec.data_ptr()
+    # the schedule this descriptor dispatches to decides the K order of the weight blob
+    p.w_layout = int(L.load().rsa_conv_weight_layout(C.byref(p)))
+    p.w_packed = wts.packed_for(p.w_layout).data_ptr()
     return p
 
 

@@ -10,8 +10,16 @@ Blob layout consumed by ``conv_kernel`` (resselt_amd/csrc/conv_mfma.hip)::
       hl  : 0 = hi (bf16 RNE of w), 1 = lo (bf16 of w - hi)   (only hl=0 when products == 1)
       lane: MFMA A-fragment lane l -> cout = 16*ct + (l & 15), cin = 32*q + 8*(l >> 4) + j
 
-Pure tensor ops: runs on whatever device ``w`` lives on and is unit-tested on CPU against the
-index formula above (tests/test_pack.py).
+The product path packs on the GPU through the C-ABI (``rsa_pack_weights``, csrc/pack.hip; ``ops.pack_weights_device``).
+The functions here are the torch restatement of the two blob layouts: host-side documentation of the format, checked on CPU
+against the index formulas (tests/test_pack_and_capi.py) and used by the GPU tests as the expected output of ``rsa_pack_weights``.
+
+Layout 1 (tap-pair K order of the ring schedule, csrc/conv_ring.h), 3x3 / three products / whole chunks only::
+
+    packed[q][s][ct][hl][lane][j],  s = 0..8;  lane group lg = lane >> 4, h = lg >> 1, plane-in-half = lg & 1
+      half A = planes 4q, 4q+1; half B = planes 4q+2, 4q+3
+      s = 0,1,2: half A, tap (ky = s,   kx = h)     s = 3: half A, tap (ky = h, kx = 2)     s = 4: tap (2,2) of half A (h=0) / B (h=1)
+      s = 5,6,7: half B, tap (ky = s-5, kx = h)     s = 8: half B, tap (ky = h, kx = 2)
 """
 
 from __future__ import annotations
@@ -55,6 +63,36 @@ def pack_conv_weights(w: torch.Tensor, cin_planes: int, products: int = 3) -> to
 
     parts = [frag(hi)] + ([frag(lo)] if products == 3 else [])
     return torch.stack(parts, dim=3).contiguous()
+
+
+def pair_layout_index(s: int, lg: int) -> tuple[int, int, int]:
+    """(plane within the 4-plane chunk, ky, kx) read by lane group ``lg`` in K step ``s`` of the tap-pair layout."""
+    h = lg >> 1
+    half = 0 if s < 4 else (h if s == 4 else 1)
+    ss = s if s < 4 else (4 if s == 4 else s - 5)
+    ky, kx = (ss, h) if ss < 3 else ((h, 2) if ss == 3 else (2, 2))
+    return 2 * half + (lg & 1), ky, kx
+
+
+def pack_conv_weights_pairs(w: torch.Tensor, cin_planes: int) -> torch.Tensor:
+    """OIHW f32 3x3 weights -> blob in the tap-pair layout (three products)."""
+    cout, cin, k, _ = w.shape
+    if k != 3 or cin_planes % 4 or cin > 8 * cin_planes:
+        raise ValueError('the tap-pair layout needs a 3x3 layer with whole 32-channel chunks')
+    ct = (cout + 15) // 16
+    q = cin_planes // 4
+    wp = torch.zeros((ct * 16, q * 32, 3, 3), dtype=torch.float32, device=w.device)
+    wp[:cout, :cin] = w.to(torch.float32)
+    hi, lo = split_bf16(wp)
+    out = torch.zeros((q, 9, ct, 2, 64, 8), dtype=torch.bfloat16, device=w.device)
+    for s in range(9):
+        for lg in range(4):
+            pl, ky, kx = pair_layout_index(s, lg)
+            for hl, src in enumerate((hi, lo)):
+                # [ct*16, q*32] -> [q, ct, 16 lanes, 8]
+                v = src[:, :, ky, kx].reshape(ct, 16, q, 4, 8)[:, :, :, pl, :].permute(2, 0, 1, 3)
+                out[:, s, :, hl, lg * 16 : lg * 16 + 16, :] = v
+    return out.contiguous()
 
 
 def pad_bias(b: torch.Tensor | None, cout: int, device) -> torch.Tensor:

@@ -38,11 +38,13 @@ class Tile:
 
 
 def _splits(total: int, parts: int, align: int) -> list[int]:
-    """Boundaries of `parts` near-equal chunks of [0, total), interior boundaries rounded to `align`."""
+    """Boundaries of at most `parts` near-equal chunks of [0, total), interior boundaries rounded to `align`.
+    A dimension too small for `parts` aligned chunks yields fewer (never an empty chunk)."""
     edges = [0]
     for i in range(1, parts):
         e = round(total * i / parts / align) * align
-        edges.append(min(max(e, edges[-1]), total))
+        if edges[-1] < e < total:
+            edges.append(e)
     edges.append(total)
     return edges
 
@@ -70,8 +72,8 @@ def plan_tiles(height: int, width: int, rows: int, cols: int, halo: int = 32, al
         halo = (halo // align + 1) * align
     ys, xs = _splits(height, rows, align), _splits(width, cols, align)
     tiles = []
-    for r in range(rows):
-        for c in range(cols):
+    for r in range(len(ys) - 1):
+        for c in range(len(xs) - 1):
             y0, y1, x0, x1 = ys[r], ys[r + 1], xs[c], xs[c + 1]
             tiles.append(Tile(len(tiles), y0, y1, x0, x1, max(y0 - halo, 0), min(y1 + halo, height), max(x0 - halo, 0), min(x1 + halo, width)))
     return tiles

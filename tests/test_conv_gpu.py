@@ -207,3 +207,74 @@ def test_argument_errors(device):
     p.ksize = 5
     with pytest.raises(RuntimeError, match='ksize'):
         ops.run_convs([p], device)
+
+
+@pytest.mark.parametrize('layout', [0, 1])
+def test_pack_weights_kernel_matches_torch_packers(device, layout):
+    """rsa_pack_weights (csrc/pack.hip) against the torch restatement of both blob layouts (engine/pack.py)."""
+    from resselt_amd.engine import pack
+
+    for cout, cin, planes, k, products in [(27, 61, 8, 3, 3), (64, 192, 24, 3, 3)] + ([] if layout else [(3, 64, 8, 3, 1), (720, 240, 30, 1, 3), (20, 11, 2, 3, 3)]):
+        w = _rand((cout, cin, k, k), cout + cin)
+        got = ops.pack_weights_device(w.to(device), planes, products, layout).cpu()
+        want = pack.pack_conv_weights_pairs(w, planes) if layout else pack.pack_conv_weights(w, planes, products)
+        assert got.numel() == want.numel()
+        assert torch.equal(got.view(torch.int16), want.reshape(-1).view(torch.int16)), (layout, cout, cin, k, products)
+
+
+@pytest.mark.parametrize(
+    'n,cin,cout,h,w,up',
+    [
+        (1, 160, 32, 530, 1000, False),  # 1088 tiles: every workgroup runs 4-5 tiles (odd counts), both streams, ragged right/bottom edges
+        (2, 64, 32, 200, 300, False),    # batch 2, 260 tiles: 252 workgroups with one tile, 4 with two
+        (1, 192, 64, 270, 480, False),   # one-stream shape, 6 chunks, 510 tiles
+        (1, 64, 64, 180, 260, True),     # nearest x2 folded into the loader (source 90 x 130)
+        (1, 96, 24, 40, 70, False),      # cout not a multiple of 16: padded cout rows are zero weights
+    ],
+)
+def test_conv_ring_schedule_whole_map(device, n, cin, cout, h, w, up):
+    """The ring schedule (csrc/conv_ring.h) over maps with many tiles per workgroup, compared over the WHOLE map."""
+    x = _rand((n, cin, h // 2, w // 2) if up else (n, cin, h, w), 21)
+    wt = _rand((cout, cin, 3, 3), 22, 1.0 / (cin * 9) ** 0.5)
+    b = _rand((cout,), 23, 0.1)
+    ref = F.leaky_relu(_ref_conv(x, wt, b, up=up), 0.2)
+    wts = ops.ConvWeights.from_oihw(wt, b, 3, device=device)
+    xin = tensors.nchw_to_planes(x.to(device))
+    out = tensors.Planes.empty(n, (cout + 7) // 8, h, w, device)
+    of32 = tensors.empty_f32map(n, cout, h, w, device)
+    p = ops.conv_params(wts, xin, h, w, upsample2x=up, out=out, out_f32=of32, act=L.ACT_LRELU, act_param=0.2)
+    assert p.w_layout == 1 and 'conv_ring' in L.conv_kernel_name(p)
+    before = L.ring_aborts()
+    ops.run_convs([p], device)
+    torch.cuda.synchronize()
+    assert L.ring_aborts() == before == 0
+    _check(tensors.f32map_to_nchw(of32, cout), ref, 3, 'ring f32')
+    got = tensors.planes_to_nchw(out, cout)
+    assert (got.cpu() - ref).abs().max().item() <= 1.5e-5 * ref.abs().max().item() * 1.5
+
+
+def test_conv_ring_agrees_with_lockstep_schedule(device):
+    """Same layer through the ring schedule and (rsa_debug_set_ring(0)) through the chunk-barrier kernels: both within tolerance of
+    torch and of each other (the K order differs, so not bit-equal)."""
+    n, cin, cout, h, w = 1, 128, 32, 90, 170
+    x = _rand((n, cin, h, w), 31)
+    wt = _rand((cout, cin, 3, 3), 32, 1.0 / (cin * 9) ** 0.5)
+    ref = _ref_conv(x, wt, None)
+    wts = ops.ConvWeights.from_oihw(wt, None, 3, device=device)
+    xin = tensors.nchw_to_planes(x.to(device))
+    outs = []
+    lib = L.load()
+    try:
+        for mode in (1, 0):
+            lib.rsa_debug_set_ring(mode)
+            of32 = tensors.empty_f32map(n, cout, h, w, device)
+            p = ops.conv_params(wts, xin, h, w, out_f32=of32)
+            assert p.w_layout == mode
+            ops.run_convs([p], device)
+            torch.cuda.synchronize()
+            outs.append(tensors.f32map_to_nchw(of32, cout).cpu())
+    finally:
+        lib.rsa_debug_set_ring(-1)
+    for o in outs:
+        _check(o, ref, 3, 'schedule')
+    assert (outs[0] - outs[1]).abs().max().item() <= 2e-5 * ref.abs().max().item()

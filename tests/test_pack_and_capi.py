@@ -56,7 +56,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(L.lib_path())
     for name in declared:
         assert hasattr(lib, name), name
-    assert L.load().rsa_version() == 100
+    assert L.load().rsa_version() == 200
 
 
 def test_conv_params_struct_matches_header_field_order():
@@ -96,3 +96,26 @@ def test_layout_reference_conversions_roundtrip():
     assert tensors.planes_to_nchw(pl, 16)[:, 13:].abs().max() == 0
     m = tensors.nchw_to_f32map(x)
     assert m.shape == (2, 4, 5, 7, 4) and torch.equal(tensors.f32map_to_nchw(m, 13), x)
+
+
+def test_pair_layout_matches_index_formula():
+    g = torch.Generator().manual_seed(5)
+    cout, cin, planes = 27, 61, 8
+    w = torch.randn((cout, cin, 3, 3), generator=g)
+    blob = pack.pack_conv_weights_pairs(w, planes)
+    assert tuple(blob.shape) == (2, 9, 2, 2, 64, 8)
+    hi = _bf16(w)
+    lo = _bf16(w - hi.float())
+    seen = set()
+    rng = torch.Generator().manual_seed(2)
+    for _ in range(600):
+        q, s, ct, hl, lane, j = (int(torch.randint(0, n, (1,), generator=rng)) for n in (2, 9, 2, 2, 64, 8))
+        pl, ky, kx = pack.pair_layout_index(s, lane >> 4)
+        co, ci = 16 * ct + (lane & 15), 32 * q + 8 * pl + j
+        want = (hi, lo)[hl][co, ci, ky, kx].item() if co < cout and ci < cin else 0.0
+        assert blob[q, s, ct, hl, lane, j].item() == want
+    # the nine steps cover every (plane, tap) pair of a chunk exactly once
+    for s in range(9):
+        for lg in range(4):
+            seen.add(pack.pair_layout_index(s, lg))
+    assert len(seen) == 36 and seen == {(pl, ky, kx) for pl in range(4) for ky in range(3) for kx in range(3)}
