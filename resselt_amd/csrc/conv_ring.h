@@ -281,6 +281,22 @@ __global__ __launch_bounds__((8 + STREAMS) * 64, 3) void conv_ring(const rsa_con
   int uB2 = uA2 + SLOT;
   int uS = slotA0 + lane_u + 2 * IW + 2 + hsel * SLOT;
 
+  // De-phase the two waves that share a SIMD (waves w and w + 4), so that one's epilogue (vector ALU + stores, no matrix work) lies
+  // beside the other's multiply instead of both storing at once with the matrix pipes idle:
+  //   STREAMS == 2: the streams are independent; stream 1 starts about half a tile late (the offset then persists);
+  //   STREAMS == 1: waves 4-7 get the lower priority, fall behind by as much as the ring allows (two chunks) and stay there.
+#ifndef RSA_RING_STAGGER
+#define RSA_RING_STAGGER 1
+#endif
+  if (RSA_RING_STAGGER) {
+    if (STREAMS == 2) {
+      if (g == 1)
+        for (int d = 0; d < nchunks * RSA_RING_STAGGER; ++d) __builtin_amdgcn_s_sleep(100);  // ~6400 cycles each
+    } else if (wave < 4) {
+      __builtin_amdgcn_s_setprio(1);
+    }
+  }
+
   load_w(0);
   uint32_t cnt = 0;  // chunks this stream has consumed
   for (int j = (STREAMS == 2 ? g : 0); j < ntw; j += STREAMS) {

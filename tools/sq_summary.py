@@ -13,10 +13,10 @@ def agg(db):
     out = collections.defaultdict(lambda: collections.defaultdict(float))
     n, dur = collections.Counter(), collections.defaultdict(float)
     for k, c, v in con.execute('select kernel_name, counter_name, value from counters_collection'):
-        if 'conv_kernel' in k:
+        if 'conv_' in k:
             out[k.split('(')[0].replace('void rsa::', '')][c] += v
     for k, d in con.execute('select name, duration from kernels'):
-        if 'conv_kernel' in k:
+        if 'conv_' in k:
             fam = k.split('(')[0].replace('void rsa::', '')
             n[fam] += 1
             dur[fam] += d
