@@ -57,6 +57,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-crop', type=int, default=256)
     ap.add_argument('--halo', type=int, default=32)
+    ap.add_argument('--no-kernel-roofline', action='store_true', help='skip the per-kernel replays (profiling runs: keeps the launch mix that of plain forwards)')
+    ap.add_argument('--dry-run', action='store_true', help='launcher / rendezvous check without a GPU: ranks meet over gloo, rank 0 prints a stub line')
     ap.add_argument('--config', default='c2', choices=['c2', 'c5'], help='c2: N tiles of 1080p (weak scaling); c5: one 4320x7680 input, 2x4 tiles (strong scaling)')
     return ap.parse_args()
 
@@ -193,6 +195,24 @@ def kernel_classes(model, reps: int) -> list:
     return sorted(out, key=lambda c: -c['ms_per_forward'])
 
 
+def dry_run(args, world: int, rank: int) -> None:
+    """No GPU work: proves that the ranks start, meet (gloo), agree on a max-over-ranks time and that rank 0's line reaches the caller."""
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo')
+        dist.barrier()
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t.item()) == float(world)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({'metric': 'output megapixels/sec, RealESRGAN-x4plus 1080p\u21924K, 1/2/4/8 MI355X', 'value': None, 'n_gpus': world, 'dry_run': True,
+                          'config': {'workload': args.config}}), flush=True)  # fmt: skip
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -206,6 +226,8 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE={world} of the launcher')
     if args.config == 'c5' and 8 % world:
         raise SystemExit('--config c5 has 8 tiles: --gpus must divide 8')
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the engine has no CPU path')
     # RSA_DIST_BACKEND=gloo rehearses the N > 1 code path with several ranks on ONE GPU (RCCL refuses two ranks per device)
@@ -307,7 +329,11 @@ def main():
         achieved_gbs = HBM_B_PER_OUT_PX * out_px / kern_s / 1e9
         layout_bytes = model.conv_bytes_per_forward()  # same layer-wise model, priced in this engine's split-plane/f32-map layouts
         nprod = 3 if args.precision == 'bf16x3' else 1
-        classes = kernel_classes(model, max(2, min(args.steps, 5)))
+        if args.no_kernel_roofline:
+            classes = [{'kernel': 'all conv launches of one forward (per-kernel replays skipped)', 'launches': n_launch, 'avg_us': round(kern_s / n_launch * 1e6, 2),
+                        'ms_per_forward': round(kern_s * 1e3, 3), 'flop_per_launch': round(flop / n_launch), 'tflops': round(achieved_tf, 2)}]  # fmt: skip
+        else:
+            classes = kernel_classes(model, max(2, min(args.steps, 5)))
         dom = max(classes, key=lambda c: c['ms_per_forward'])
         traffic = measured_traffic() if (args.precision == 'bf16x3' and (H, W, args.blocks) == (1080, 1920, 23)) else {'bytes': None, 'note': 'PMC traffic is only collected for the default workload'}
         tile_note = {

@@ -120,6 +120,15 @@ typedef struct rsa_conv_params {
                                UNPADDED input under a padded / unshuffled convolution grid (rtmosr/arch.py:383-387) */
   int32_t out_base_h, out_base_w;
   int32_t w_layout;         /* layout of w_packed: must equal rsa_conv_weight_layout(this descriptor); see rsa_pack_weights */
+  /* Residual operands as SPLIT PLANES instead of f32 maps (value = hi + lo, ~16 bits): the residual stream of a residual dense block
+   * is then stored once (the planes the next convolution reads) instead of twice.  res1_hi excludes res1, res2_hi excludes res2;
+   * the planes start at the residual's channel 0; strides in 16-byte units, shared by both; lo pointers may be NULL (hi only). */
+  const void* res1_hi;
+  const void* res1_lo;
+  const void* res2_hi;
+  const void* res2_lo;
+  int64_t res_plane_stride;
+  int64_t res_batch_stride;
 } rsa_conv_params;
 
 /* Launch `n` fused convolutions in order on `stream` (one host call per forward pass). */

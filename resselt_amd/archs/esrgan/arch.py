@@ -101,6 +101,7 @@ class RRDBNet(EngineModule):
         self.plus = plus
         self.shuffle_factor = shuffle_factor
         self.scale = scale // shuffle_factor if shuffle_factor else scale
+        self.plane_residuals = True  # residual stream kept as split planes only (False: the f32-map plan; A/B and plain-bf16 mode)
         build_param_tree(self, rrdbnet_param_shapes(in_nc, out_nc, num_filters, num_blocks, scale, plus))
 
     def _convert_state_dict(self, state_dict):
@@ -150,16 +151,23 @@ class RRDBNet(EngineModule):
         with_lo = products == 3
         pf, pg = nf // 8, gc // 8
         x_pl = plan.planes(n, (c_net + 7) // 8, h, w, with_lo)
-        ws = [plan.planes(n, pf + 4 * pg, h, w, with_lo) for _ in range(2)]
+        # The residual stream x of the RDBs lives ONLY as the split planes the next convolution reads (hi + lo, ~16 bits; measured
+        # cost of rounding it there instead of keeping an f32 copy: 3e-5 max-abs on RRDBNet-23): conv5 takes `x5*0.2 + x` and the
+        # RRDB's `out*0.2 + x` from planes.  Three workspaces rotate inside an RRDB: RDB1 0 -> 1, RDB2 1 -> 2, RDB3 2 -> 0, so the RRDB
+        # input (workspace 0, planes 0..pf) is still intact when RDB3's conv5 adds it, and is then overwritten in place by that
+        # same launch (each lane reads its residual elements before it stores them).  Plain-bf16 mode has no lo planes and keeps
+        # the f32 residual maps (a bf16 residual stream would lose what little accuracy that mode has).
+        plane_res = with_lo and self.plane_residuals
+        ws = [plan.planes(n, pf + 4 * pg, h, w, with_lo) for _ in range(3 if plane_res else 2)]
         fea = plan.f32map(n, nf, h, w)
-        pool = [plan.f32map(n, nf, h, w) for _ in range(4)]
+        pool = [] if plane_res else [plan.f32map(n, nf, h, w) for _ in range(4)]
         lrelu = dict(act=L.ACT_LRELU, act_param=0.2)
 
         def set_input(x):
             # reflect padding + pixel_unshuffle (when the checkpoint has the unshuffle front end) happen inside the layout kernel
             ops.nchw_to_planes(x, x_pl, unshuffle=sf or 1)
 
-        # fea conv (arch.py:74-80): split planes into workspace 0 and the f32 residual stream
+        # fea conv (arch.py:74-80): split planes into workspace 0 and the f32 copy the trunk shortcut adds at the end
         plan.conv(ops.conv_params(W['model.0'], x_pl, h, w, out=ws[0], out_plane_off=0, out_f32=fea))
         cur_f32, cur_ws = fea, 0
         free = list(pool)
@@ -170,7 +178,8 @@ class RRDBNet(EngineModule):
             taken = []
             for r in (1, 2, 3):
                 p = f'model.1.sub.{i}.RDB{r}'
-                a, b = ws[cur_ws], ws[cur_ws ^ 1]
+                nxt_ws = (r % 3) if plane_res else cur_ws ^ 1
+                a, b = ws[cur_ws], ws[nxt_ws]
                 for j in range(1, 5):
                     kw = dict(cin_planes=pf + (j - 1) * pg, out=a, out_plane_off=pf + (j - 1) * pg, **lrelu)
                     if self.plus and j == 2:
@@ -180,17 +189,24 @@ class RRDBNet(EngineModule):
                     if self.plus and j == 4:
                         kw.update(res1=x2_f32, alpha=1.0)
                     plan.conv(ops.conv_params(W[f'{p}.conv{j}.0'], a, h, w, **kw))
-                nxt = free.pop()
-                taken.append(nxt)
-                kw = dict(cin_planes=pf + 4 * pg, res1=cur_f32, alpha=0.2, out=b, out_plane_off=0, out_f32=nxt)
-                if r == 3:
-                    kw.update(res2=rrdb_in, beta=0.2)  # RRDB.forward: out*0.2 + x (block.py:340-344)
+                if plane_res:
+                    kw = dict(cin_planes=pf + 4 * pg, res1=(a, 0), alpha=0.2, out=b, out_plane_off=0)
+                    if r == 3:
+                        kw.update(res2=(ws[0], 0), beta=0.2)  # RRDB.forward: out*0.2 + x (block.py:340-344); ws[0] is also `b`
+                else:
+                    nxt = free.pop()
+                    taken.append(nxt)
+                    kw = dict(cin_planes=pf + 4 * pg, res1=cur_f32, alpha=0.2, out=b, out_plane_off=0, out_f32=nxt)
+                    if r == 3:
+                        kw.update(res2=rrdb_in, beta=0.2)
+                    cur_f32 = nxt
                 plan.conv(ops.conv_params(W[f'{p}.conv5.0'], a, h, w, **kw))
-                cur_f32, cur_ws = nxt, cur_ws ^ 1
-            # recycle f32 maps: everything except the RRDB output
-            if rrdb_in is not fea:
-                free.append(rrdb_in)
-            free.extend(taken[:2])
+                cur_ws = nxt_ws
+            if not plane_res:
+                # recycle f32 maps: everything except the RRDB output
+                if rrdb_in is not fea:
+                    free.append(rrdb_in)
+                free.extend(taken[:2])
         # trunk conv + ShortcutBlock (block.py:83-91)
         u = plan.planes(n, pf, h, w, with_lo)
         plan.conv(ops.conv_params(W[f'model.1.sub.{nb}'], ws[cur_ws], h, w, cin_planes=pf, res1=fea, alpha=1.0, out=u))

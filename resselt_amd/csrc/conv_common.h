@@ -156,6 +156,16 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
 
   // Residual fragments are fetched ONE STEP AHEAD (a step = one pixel-tile pair of one cout tile): the loads of step s+1 are issued
   // before the stores of step s, so they never queue behind a store of this epilogue (vmcnt retires in order and counts stores).
+  // A residual is either an f32 map (res1 / res2) or split planes (res1_hi / res1_lo ...: value = hi + lo).  Plane residuals arrive
+  // as two 8-byte halves of a unit (this lane's 4 channels) and are widened to f32 here, so the arithmetic below sees one form.
+  const bool has_r1 = p.res1 != nullptr || p.res1_hi != nullptr;
+  const bool has_r2 = p.res2 != nullptr || p.res2_hi != nullptr;
+  auto widen = [](uint2 h, uint2 l) -> f32x4 {
+    return (f32x4){__builtin_bit_cast(float, h.x << 16) + __builtin_bit_cast(float, l.x << 16),
+                   __builtin_bit_cast(float, h.x & 0xffff0000u) + __builtin_bit_cast(float, l.x & 0xffff0000u),
+                   __builtin_bit_cast(float, h.y << 16) + __builtin_bit_cast(float, l.y << 16),
+                   __builtin_bit_cast(float, h.y & 0xffff0000u) + __builtin_bit_cast(float, l.y & 0xffff0000u)};
+  };
   f32x4 nr1[2], nr2[2];
   auto fetch_res = [&](int ct, int pp) {
     const int cbase = (ctile0 + ct) * 16;
@@ -163,15 +173,29 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
     const bool cok = (wct * CTW + ct < NCT) && c0 < cout8 && c0 < (p4 << 2);
     const char* r1b = (const char*)p.res1 + (((int64_t)n * p4 + (cbase >> 2)) * HW + pix0) * 16;
     const char* r2b = (const char*)p.res2 + (((int64_t)n * p4 + (cbase >> 2)) * HW + pix0) * 16;
+    // plane residuals: unit (plane cbase/8 + lg/2, pixel), half lg & 1
+    const int64_t runit0 = (int64_t)n * p.res_batch_stride + (int64_t)(cbase >> 3) * p.res_plane_stride + pix0;
+    const uint32_t rlane = (uint32_t)(lg >> 1) * (uint32_t)p.res_plane_stride;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int pt = pp * 2 + e;
       const bool okl = pvalid_of(pt) && cok;
       const uint32_t foff = ((uint32_t)lg * (uint32_t)HW + lpix_of(pt)) * 16u;
+      const uint32_t poff = (rlane + lpix_of(pt)) * 16u + (uint32_t)(lg & 1) * 8u;
       nr1[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
       nr2[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (p.res1 != nullptr && okl) nr1[e] = *(const f32x4*)(r1b + foff);
       if (p.res2 != nullptr && okl) nr2[e] = *(const f32x4*)(r2b + foff);
+      if (p.res1_hi != nullptr && okl) {
+        const uint2 h = *(const uint2*)((const char*)p.res1_hi + runit0 * 16 + poff);
+        const uint2 l = p.res1_lo != nullptr ? *(const uint2*)((const char*)p.res1_lo + runit0 * 16 + poff) : make_uint2(0u, 0u);
+        nr1[e] = widen(h, l);
+      }
+      if (p.res2_hi != nullptr && okl) {
+        const uint2 h = *(const uint2*)((const char*)p.res2_hi + runit0 * 16 + poff);
+        const uint2 l = p.res2_lo != nullptr ? *(const uint2*)((const char*)p.res2_lo + runit0 * 16 + poff) : make_uint2(0u, 0u);
+        nr2[e] = widen(h, l);
+      }
     }
   };
   if (OUTK == 0) fetch_res(0, 0);
@@ -232,13 +256,13 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
           } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[e][r] = act_apply<AC>(v[e][r], p.act, p.act == RSA_ACT_PRELU ? slope[r] : p.act_param);
-            if (p.res1 != nullptr && has_f32grp && ok[e]) {
+            if (has_r1 && has_f32grp && ok[e]) {
               const f32x4 rr = cr1[e];
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[e][r] = v[e][r] * p.alpha + rr[r];
             }
           }
-          if (p.res2 != nullptr && has_f32grp && ok[e]) {
+          if (has_r2 && has_f32grp && ok[e]) {
             const f32x4 rr = cr2[e];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[e][r] = v[e][r] * p.beta + rr[r];

@@ -54,19 +54,25 @@ int conv_launch(const rsa_conv_params& p, hipStream_t stream) {
   if (p.upsample2x && (p.ksize != 3 || (p.H & 1) || (p.W & 1))) return set_error(RSA_E_UNSUPPORTED, "conv: upsample2x needs k3 and even H, W");
   if (p.in_hi == nullptr || p.w_packed == nullptr) return set_error(RSA_E_ARG, "conv: null input/weights");
   if (p.products == 3 && p.in_lo == nullptr) return set_error(RSA_E_ARG, "conv: products=3 needs in_lo");
-  if (p.act == RSA_ACT_SPAB_GATE && p.res1 == nullptr) return set_error(RSA_E_ARG, "conv: SPAB gate needs res1");
+  if (p.act == RSA_ACT_SPAB_GATE && p.res1 == nullptr && p.res1_hi == nullptr) return set_error(RSA_E_ARG, "conv: SPAB gate needs res1");
+  if ((p.res1 != nullptr && p.res1_hi != nullptr) || (p.res2 != nullptr && p.res2_hi != nullptr))
+    return set_error(RSA_E_ARG, "conv: a residual is either an f32 map or split planes, not both");
+  if ((p.res1_lo != nullptr && p.res1_hi == nullptr) || (p.res2_lo != nullptr && p.res2_hi == nullptr)) return set_error(RSA_E_ARG, "conv: residual lo planes without hi planes");
+  if ((p.res1_hi != nullptr || p.res2_hi != nullptr) && (p.res_plane_stride * 32 >= (int64_t)1 << 32 || (p.cout & 7)))
+    return set_error(RSA_E_UNSUPPORTED, "conv: plane residuals need cout % 8 == 0 and planes below 128 Mpx");
   if (p.act < 0 || p.act > RSA_ACT_PRELU) return set_error(RSA_E_ARG, "conv: bad act");
   if (p.act == RSA_ACT_PRELU && (p.act_vec == nullptr || ((uintptr_t)p.act_vec & 15))) return set_error(RSA_E_ARG, "conv: PReLU needs 16-byte aligned act_vec");
   if (p.out_base != nullptr && p.out_nchw == nullptr) return set_error(RSA_E_ARG, "conv: out_base only applies to the out_nchw store");
   if (((uintptr_t)p.in_hi | (uintptr_t)p.in_lo | (uintptr_t)p.w_packed | (uintptr_t)p.out_hi | (uintptr_t)p.out_lo | (uintptr_t)p.out_f32 |
-       (uintptr_t)p.res1 | (uintptr_t)p.res2) & 15)
+       (uintptr_t)p.res1 | (uintptr_t)p.res2 | (uintptr_t)p.res1_hi | (uintptr_t)p.res1_lo | (uintptr_t)p.res2_hi | (uintptr_t)p.res2_lo) & 15)
     return set_error(RSA_E_ALIGN, "conv: pointers must be 16-byte aligned");
   if (p.in_plane_stride * 64 >= (int64_t)1 << 32) return set_error(RSA_E_UNSUPPORTED, "conv: input plane too large for a 4-plane buffer descriptor (>= 64 Mpx); band the image");
   if (p.out_plane_stride * 32 >= (int64_t)1 << 32 || (int64_t)p.H * p.W * 64 >= (int64_t)1 << 32)
     return set_error(RSA_E_UNSUPPORTED, "conv: output plane too large for 32-bit lane offsets; band the image");
   if ((uintptr_t)p.bias & 15) return set_error(RSA_E_ALIGN, "conv: bias must be 16-byte aligned (and padded to a multiple of 16 floats)");
   if (p.out_nchw != nullptr) {
-    if (p.out_hi != nullptr || p.out_f32 != nullptr || p.res1 != nullptr || p.res2 != nullptr || p.act == RSA_ACT_SPAB_GATE)
+    if (p.out_hi != nullptr || p.out_f32 != nullptr || p.res1 != nullptr || p.res2 != nullptr || p.res1_hi != nullptr || p.res2_hi != nullptr ||
+        p.act == RSA_ACT_SPAB_GATE)
       return set_error(RSA_E_UNSUPPORTED, "conv: out_nchw is a final store: no plane/f32 outputs or residuals with it");
     const int ps = p.pixel_shuffle > 1 ? p.pixel_shuffle : 1;
     if (p.cout % (ps * ps) != 0) return set_error(RSA_E_ARG, "conv: cout not divisible by pixel_shuffle^2");

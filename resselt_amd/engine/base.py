@@ -28,7 +28,7 @@ def conv_algorithmic_bytes(p: L.ConvParams) -> int:
     px_in = px_out // 4 if p.upsample2x else px_out
     total = p.cin_planes * 16 * (2 if p.products == 3 else 1) * px_in
     maps = (p.cout + 3) // 4 * 16 * px_out
-    total += maps * sum(1 for r in (p.res1, p.res2, p.out_f32) if r)
+    total += maps * sum(1 for r in (p.res1, p.res2, p.out_f32, p.res1_hi, p.res2_hi) if r)  # plane residuals: hi + lo = the same 4 B / channel
     if p.out_hi:
         total += (p.cout + 7) // 8 * 16 * (2 if p.out_lo else 1) * px_out
     if p.out_nchw:

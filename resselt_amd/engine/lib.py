@@ -61,6 +61,12 @@ class ConvParams(C.Structure):
         ('out_base_h', C.c_int32),
         ('out_base_w', C.c_int32),
         ('w_layout', C.c_int32),
+        ('res1_hi', C.c_void_p),
+        ('res1_lo', C.c_void_p),
+        ('res2_hi', C.c_void_p),
+        ('res2_lo', C.c_void_p),
+        ('res_plane_stride', C.c_int64),
+        ('res_batch_stride', C.c_int64),
     ]
 
 

@@ -100,9 +100,9 @@ def conv_params(
     upsample2x: bool = False,
     act: int = L.ACT_NONE,
     act_param: float = 0.0,
-    res1: torch.Tensor | None = None,
+    res1: 'torch.Tensor | tuple[Planes, int] | None' = None,
     alpha: float = 1.0,
-    res2: torch.Tensor | None = None,
+    res2: 'torch.Tensor | tuple[Planes, int] | None' = None,
     beta: float = 1.0,
     out: Planes | None = None,
     out_plane_off: int = 0,
@@ -143,12 +143,26 @@ def conv_params(
     p.alpha = alpha
     p.beta = beta
     p4 = (wts.cout + 3) // 4
+    # a residual is an f32 map, or split planes given as (Planes, first plane): value = hi + lo
+    plane_res = {}
+    for name, r in (('res1', res1), ('res2', res2)):
+        if isinstance(r, tuple):
+            pl, plane0 = r
+            if (pl.n, pl.h, pl.w) != (x.n, H, W) or plane0 + (wts.cout + 7) // 8 > pl.planes or wts.cout % 8:
+                raise ValueError(f'{name}: plane residual does not match the convolution output')
+            plane_res[name] = (pl, plane0)
+    if len({(pl.plane_stride, pl.batch_stride) for pl, _ in plane_res.values()}) > 1:
+        raise ValueError('res1 and res2 plane residuals must share their strides')
     for name, r in (('res1', res1), ('res2', res2), ('out_f32', out_f32)):
-        if r is not None:
+        if r is not None and name not in plane_res:
             if tuple(r.shape) != (x.n, p4, H, W, 4) or r.dtype != torch.float32 or not r.is_contiguous():
                 raise ValueError(f'{name} must be a contiguous f32 [N,{p4},{H},{W},4] map, got {tuple(r.shape)} {r.dtype}')
-    p.res1 = None if res1 is None else res1.data_ptr()
-    p.res2 = None if res2 is None else res2.data_ptr()
+    p.res1 = None if res1 is None or 'res1' in plane_res else res1.data_ptr()
+    p.res2 = None if res2 is None or 'res2' in plane_res else res2.data_ptr()
+    for name, (pl, plane0) in plane_res.items():
+        setattr(p, f'{name}_hi', pl.hi_ptr(plane0))
+        setattr(p, f'{name}_lo', pl.lo_ptr(plane0))
+        p.res_plane_stride, p.res_batch_stride = pl.plane_stride, pl.batch_stride
     p.out_f32 = None if out_f32 is None else out_f32.data_ptr()
     nplanes_out = (wts.cout + 7) // 8
     if out is not None:

@@ -278,3 +278,35 @@ def test_conv_ring_agrees_with_lockstep_schedule(device):
     for o in outs:
         _check(o, ref, 3, 'schedule')
     assert (outs[0] - outs[1]).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize('ring', [1, 0])
+def test_conv_rdb_epilogue_plane_residuals(device, ring):
+    """conv5 of the last RDB of an RRDB with both residuals given as split planes (value = hi + lo), the second one being the planes
+    the launch overwrites in place -- the RRDBNet plan's layout (archs/esrgan/arch.py)."""
+    n, h, w = 1, 37, 70
+    x = _rand((n, 192, h, w), 41)
+    wt = _rand((64, 192, 3, 3), 42, 1.0 / (192 * 9) ** 0.5)
+    b = _rand((64,), 43, 0.1)
+    r2 = _rand((n, 64, h, w), 44)
+    src = tensors.nchw_to_planes(x.to(device))  # residual 1 = the first 64 channels of the conv input, as in an RDB
+    dst = tensors.Planes.empty(n, 24, h, w, device)
+    r2p = tensors.nchw_to_planes(r2.to(device))
+    dst.hi[:, :8] = r2p.hi
+    dst.lo[:, :8] = r2p.lo
+    x64 = tensors.planes_to_nchw(tensors.Planes(src.hi[:, :8].contiguous(), src.lo[:, :8].contiguous()), 64).cpu()
+    r2q = tensors.planes_to_nchw(r2p, 64).cpu()
+    ref = (_ref_conv(x, wt, b) * 0.2 + x64) * 0.2 + r2q
+    wts = ops.ConvWeights.from_oihw(wt, b, 3, device=device)
+    lib = L.load()
+    try:
+        lib.rsa_debug_set_ring(ring)
+        p = ops.conv_params(wts, src, h, w, res1=(src, 0), alpha=0.2, res2=(dst, 0), beta=0.2, out=dst, out_plane_off=0)
+        assert p.w_layout == ring
+        ops.run_convs([p], device)
+        torch.cuda.synchronize()
+    finally:
+        lib.rsa_debug_set_ring(-1)
+    got = tensors.planes_to_nchw(tensors.Planes(dst.hi[:, :8].contiguous(), dst.lo[:, :8].contiguous()), 64)
+    assert (got.cpu() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
+    assert L.ring_aborts() == 0

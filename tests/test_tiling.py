@@ -99,3 +99,40 @@ def test_tile_parallel_all_gather_gloo(world):
         assert (y - full).abs().max().item() <= 1e-6, rank  # every rank ends with the whole image
         assert (y3 - full).abs().max().item() <= 1e-6, rank
         assert (y1 - full).abs().max().item() <= 1e-6, rank
+
+
+def test_bench_launcher_starts_ranks_and_relays_one_line():
+    """`python bench.py --gpus N` without torch.distributed.run starts the N ranks itself (before touching the GPU) and prints
+    exactly rank 0's JSON line; a failing child gives a non-zero exit status.  --dry-run keeps the ranks off the GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    ok = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-run'], env=env, capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    lines = [ln for ln in ok.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['dry_run'] is True
+    # --gpus that does not divide the 8 tiles of config c5: every rank exits non-zero, and so does the launcher
+    bad = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '3', '--config', 'c5', '--dry-run'], env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith('{')]
+
+
+def test_splits_never_yield_empty_tiles():
+    from resselt_amd.tiling import _splits
+
+    assert _splits(10, 4, 8) == [0, 8, 10]
+    assert _splits(5, 3, 8) == [0, 5]
+    tiles = plan_tiles(10, 20, 3, 1, halo=2, align=8)
+    assert all(t.y1 > t.y0 and t.x1 > t.x0 for t in tiles) and tiles[-1].y1 == 10
+    x = torch.arange(10 * 20, dtype=torch.float32).reshape(1, 1, 10, 20)
+    y = upscale_tiled(lambda t: t.repeat_interleave(2, -1).repeat_interleave(2, -2), x, 2, tile=(3, 20), halo=2, align=8)
+    assert torch.equal(y, x.repeat_interleave(2, -1).repeat_interleave(2, -2))
+
+
+def test_choose_grid_keeps_tile_aspect():
+    assert [choose_grid(n, 1080, 1920) for n in (1, 2, 4, 8)] == [(1, 1), (1, 2), (2, 2), (2, 4)]
