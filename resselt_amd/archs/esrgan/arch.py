@@ -101,6 +101,7 @@ class RRDBNet(EngineModule):
         self.plus = plus
         self.shuffle_factor = shuffle_factor
         self.scale = scale // shuffle_factor if shuffle_factor else scale
+        self.tail_band_rows = 272  # low-resolution rows per band of the 2x / 4x tail (bounds the plan's HR buffers; >= image height: one band)
         self.plane_residuals = True  # residual stream kept as split planes only (False: the f32-map plan; A/B and plain-bf16 mode)
         build_param_tree(self, rrdbnet_param_shapes(in_nc, out_nc, num_filters, num_blocks, scale, plus))
 
@@ -210,29 +211,71 @@ class RRDBNet(EngineModule):
         # trunk conv + ShortcutBlock (block.py:83-91)
         u = plan.planes(n, pf, h, w, with_lo)
         plan.conv(ops.conv_params(W[f'model.1.sub.{nb}'], ws[cur_ws], h, w, cin_planes=pf, res1=fea, alpha=1.0, out=u))
-        k = 3
-        hh, wwid = h, w
-        for _ in range(int(math.log2(self.net_scale))):
-            hh, wwid = hh * 2, wwid * 2
-            nu = plan.planes(n, pf, hh, wwid, with_lo)
-            plan.conv(ops.conv_params(W[f'model.{k}'], u, hh, wwid, upsample2x=True, out=nu, **lrelu))
-            u = nu
-            k += 3
-        k -= 1
-        hr = plan.planes(n, pf, hh, wwid, with_lo)
-        plan.conv(ops.conv_params(W[f'model.{k}'], u, hh, wwid, out=hr, **lrelu))
-        out_buf = {'y': torch.empty((n, self.out_nc, hh, wwid), dtype=dtype, device=plan.device)}
-        plan.conv(ops.conv_params(W[f'model.{k + 2}'], hr, hh, wwid, out_nchw=out_buf['y']))
-        arr = plan.flush()
-        last_entry = arr[len(arr) - 1]
+        # ---- tail at 2x / 4x resolution (upconv blocks, HR conv, last conv: arch.py:110-126), run in BANDS of low-resolution rows.
+        # A 64-channel map at 4x resolution is 8.5 GB per 1080p frame in split planes; three of them made the plan 25 GB.  The tail is
+        # a chain of 3x3 convolutions, so a band of rows needs a halo of 1 row per convolution at that convolution's resolution
+        # (5 rows at 4x = 2 low-resolution rows); the band is computed with that halo, zero padding only at true image borders, and the
+        # contaminated halo rows of the band's output are dropped when it is copied into the frame.
+        n_up = int(math.log2(self.net_scale))
+        s_net = 2**n_up
+        halo_lr = 2
+        band_lr = max(16, int(self.tail_band_rows))
+        n_bands = max(1, -(-h // band_lr))
+        band_lr = -(-h // n_bands)
+        sub_h = min(h, band_lr + 2 * halo_lr)  # rows of the largest band with its halo
+        bufs = []  # per resolution level: planes for `sub_h << level` rows
+        for lv in range(1, n_up + 1):
+            bufs.append(plan.planes(n, pf, sub_h << lv, w << lv, with_lo))
+        hr_buf = plan.planes(n, pf, sub_h * s_net, w * s_net, with_lo)
+        hh, wwid = h * s_net, w * s_net
+        out_buf: dict = {}
+        band_out = torch.empty(n * self.out_nc * sub_h * s_net * wwid, dtype=dtype, device=plan.device) if n_bands > 1 else None  # flat: each band views it densely
+        plan.keep.append(band_out)
+        from ...engine.tensors import PlaneRows
 
-        # a fresh output tensor per call: patch the last descriptor's pointer before launching
+        last_entries = []
+        copies = []
+        for bi in range(n_bands):
+            a0, a1 = bi * band_lr, min(h, (bi + 1) * band_lr)
+            r0, r1 = max(0, a0 - halo_lr), min(h, a1 + halo_lr)
+            rows = r1 - r0
+            src = PlaneRows(u, r0, r1) if n_bands > 1 else u
+            k = 3
+            for lv in range(1, n_up + 1):
+                dst = PlaneRows(bufs[lv - 1], 0, rows << lv) if n_bands > 1 else bufs[lv - 1]
+                plan.conv(ops.conv_params(W[f'model.{k}'], src, rows << lv, w << lv, upsample2x=True, out=dst, **lrelu))
+                src = dst
+                k += 3
+            k -= 1
+            hr = PlaneRows(hr_buf, 0, rows * s_net) if n_bands > 1 else hr_buf
+            plan.conv(ops.conv_params(W[f'model.{k}'], src, rows * s_net, wwid, out=hr, **lrelu))
+            if n_bands > 1:
+                tmp = band_out[: n * self.out_nc * rows * s_net * wwid].view(n, self.out_nc, rows * s_net, wwid)
+                plan.conv(ops.conv_params(W[f'model.{k + 2}'], hr, rows * s_net, wwid, out_nchw=tmp))
+                arr = plan.flush()
+                lo, hi_ = (a0 - r0) * s_net, (a1 - r0) * s_net
+
+                def copy_band(tmp=tmp, lo=lo, hi_=hi_, y0=a0 * s_net, y1=a1 * s_net):
+                    out_buf['y'][:, :, y0:y1] = tmp[:, :, lo:hi_]
+
+                plan.call(copy_band)
+            else:
+                placeholder = torch.empty((n, self.out_nc, hh, wwid), dtype=dtype, device=plan.device)
+                out_buf['y'] = placeholder
+                plan.conv(ops.conv_params(W[f'model.{k + 2}'], hr, hh, wwid, out_nchw=placeholder))
+                arr = plan.flush()
+                last_entries.append(arr[len(arr) - 1])
+
+        # a fresh output tensor per call (single band: patch the last descriptor's pointer; bands: the copies fill it)
         def prepare_output():
             if 'y' not in out_buf:
                 out_buf['y'] = torch.empty((n, self.out_nc, hh, wwid), dtype=dtype, device=plan.device)
-            last_entry.out_nchw = out_buf['y'].data_ptr()
+            for e in last_entries:
+                e.out_nchw = out_buf['y'].data_ptr()
 
-        plan.steps.insert(len(plan.steps) - 1, prepare_output)
+        plan.steps.insert(0, prepare_output)
+        if n_bands > 1:
+            out_buf.pop('y', None)
 
         def get_output():
             y = out_buf.pop('y')

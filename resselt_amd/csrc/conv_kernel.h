@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "conv_common.h"
 
 #ifndef RSA_XCD_STRIPS
@@ -292,13 +294,15 @@ static int launch_one(const rsa_conv_params& p, hipStream_t stream) {
   const int64_t num_tiles = (int64_t)tiles_x * tiles_y * p.batch;
   if (num_tiles > 0x7fffffff) return RSA_E_UNSUPPORTED;
   // persistent workgroups: as many as the chip keeps resident (queried once per instantiation), strided over the tiles
-  static int resident = 0;
+  static std::atomic<int> resident_cache{0};  // concurrent first calls compute the same value: idempotent, never torn
+  int resident = resident_cache.load(std::memory_order_relaxed);
   if (resident == 0) {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_kernel<KS, NCT, PROD, UP, OUTK>, G::NTHR, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipGetLastError();
     resident = per_cu * prop.multiProcessorCount;
+    resident_cache.store(resident, std::memory_order_relaxed);
   }
   (void)slabs;  // cout slabs are looped inside the kernel
   int gx = resident;

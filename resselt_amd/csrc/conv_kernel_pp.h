@@ -237,13 +237,15 @@ static int launch_pp(const rsa_conv_params& p, hipStream_t stream) {
   const int tiles_y = (p.H + G::TH - 1) / G::TH;
   const int64_t num_tiles = (int64_t)tiles_x * tiles_y * p.batch;
   if (num_tiles > 0x3fffffff) return RSA_E_UNSUPPORTED;
-  static int resident = 0;
+  static std::atomic<int> resident_cache{0};  // concurrent first calls compute the same value: idempotent, never torn
+  int resident = resident_cache.load(std::memory_order_relaxed);
   if (resident == 0) {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_kernel_pp<KS, PROD, UP, OUTK>, 576, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipGetLastError();
     resident = per_cu * prop.multiProcessorCount;
+    resident_cache.store(resident, std::memory_order_relaxed);
   }
   int gx = resident;
   if (gx > num_tiles) gx = (int)num_tiles;

@@ -10,6 +10,8 @@
 //     no other vector-memory instruction is issued in between, so the in-order vmcnt never drains the prefetch early;
 //   * one workgroup barrier per tile; 8 waves x CTW cout tiles = up to 256 output channels per pass (wider layers take
 //     ceil(cout / (128*CTW)) passes over the token map).
+#include <atomic>
+
 #include "conv_common.h"
 
 namespace rsa {
@@ -236,13 +238,15 @@ static int launch_gemm(const rsa_conv_params& p, hipStream_t stream) {
   const int64_t HW = (int64_t)p.H * p.W;
   const int64_t num_tiles = ((HW + GK_TP - 1) / GK_TP) * p.batch;
   if (num_tiles > 0x7fffffff) return RSA_E_UNSUPPORTED;
-  static int resident = 0;
+  static std::atomic<int> resident_cache{0};  // concurrent first calls compute the same value: idempotent, never torn
+  int resident = resident_cache.load(std::memory_order_relaxed);
   if (resident == 0) {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_k1_kernel<PROD, CTW, NQ, GK_TP>, GK_WAVES * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipGetLastError();
     resident = per_cu * prop.multiProcessorCount;
+    resident_cache.store(resident, std::memory_order_relaxed);
   }
   int gx = resident;
   if (gx > num_tiles) gx = (int)num_tiles;

@@ -96,9 +96,20 @@ class Plan:
         """Algorithmic HBM bytes of the convolution launches in THIS engine's layouts (see ``conv_algorithmic_bytes``)."""
         return getattr(self, '_conv_bytes', 0)
 
+    def release(self) -> None:
+        """Drop every buffer and closure now.  A plan's steps are closures over its own buffers (reference cycles), so a plan that is
+        merely dereferenced keeps its gigabytes until the cycle collector runs; the cache calls this when it evicts a plan."""
+        self._released_bytes = self.buffer_bytes()
+        self.keep.clear()
+        self.steps.clear()
+        self.conv_arrays.clear()
+        self._pending = []
+
     def buffer_bytes(self) -> int:
         total = 0
         for k in self.keep:
+            if k is None:
+                continue
             if isinstance(k, Planes):
                 total += k.hi.numel() * 2 * (2 if k.lo is not None else 1)
             elif isinstance(k, torch.Tensor):
@@ -118,11 +129,19 @@ class EngineModule(nn.Module):
         self.use_graph: bool = False
         self._packed: dict = {}
         self._plans: dict = {}
-        self._max_plans = 4
+        self._max_plans = 8
+        self.max_plan_bytes = 40 << 30  # byte budget of the cached plans' buffers (least recently used plans are dropped first)
 
     # -- cache invalidation: anything that can change parameter values, dtype or device --
+    def _drop_plan(self, key) -> None:
+        entry = self._plans.pop(key)
+        entry[0].release()
+        entry[1:] = [None, None, None]  # input setter / output getter / graph: closures over the plan's buffers
+
     def _invalidate(self) -> None:
         self._packed = {}
+        for key in list(getattr(self, '_plans', {})):
+            self._drop_plan(key)
         self._plans = {}
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
@@ -177,7 +196,8 @@ class EngineModule(nn.Module):
             with torch.no_grad():
                 w = self._pack(device, self.products)
             self._packed = {key: w}
-            self._plans = {}
+            for k in list(self._plans):
+                self._drop_plan(k)
         return w
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -190,15 +210,16 @@ class EngineModule(nn.Module):
             raise RuntimeError(f'model parameters are on {first.device} but the input is on {x.device}')
         packed = self._weights(x.device)
         key = (tuple(x.shape), x.dtype, str(x.device), self.products)
-        entry = self._plans.get(key)
+        entry = self._plans.pop(key, None)
         if entry is None:
-            if len(self._plans) >= self._max_plans:
-                self._plans.pop(next(iter(self._plans)))
             plan = Plan(x.device)
             set_input, get_output = self._build_plan(plan, packed, tuple(x.shape), x.dtype, self.products)
             plan.flush()
             entry = [plan, set_input, get_output, None]
-            self._plans[key] = entry
+        self._plans[key] = entry  # most recently used last
+        # least-recently-used plans go first when the cache holds too many plans or too many bytes (never the one about to run)
+        while len(self._plans) > 1 and (len(self._plans) > self._max_plans or sum(e[0].buffer_bytes() for e in self._plans.values()) > self.max_plan_bytes):
+            self._drop_plan(next(iter(self._plans)))
         plan, set_input, get_output, graph = entry
         with torch.cuda.device(x.device):
             if not self.use_graph:

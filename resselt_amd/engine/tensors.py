@@ -58,6 +58,31 @@ class Planes:
         return self.lo.data_ptr() + plane * self.plane_stride * 16
 
 
+class PlaneRows:
+    """Rows [r0, r1) of a ``Planes`` buffer as a convolution operand: same storage and strides, first-row pointer offset.
+    Lets a plan run part of a network band by band (bounded buffers at 2x / 4x resolution) without copying."""
+
+    def __init__(self, base: Planes, r0: int, r1: int):
+        if not 0 <= r0 < r1 <= base.h:
+            raise ValueError(f'rows [{r0}, {r1}) outside a map of {base.h} rows')
+        self.base, self.r0, self.r1 = base, r0, r1
+        self.hi, self.lo = base.hi, base.lo  # (the whole tensors: kept alive by whoever holds the view)
+
+    n = property(lambda self: self.base.n)
+    planes = property(lambda self: self.base.planes)
+    w = property(lambda self: self.base.w)
+    h = property(lambda self: self.r1 - self.r0)
+    plane_stride = property(lambda self: self.base.plane_stride)
+    batch_stride = property(lambda self: self.base.batch_stride)
+
+    def hi_ptr(self, plane: int = 0) -> int:
+        return self.base.hi_ptr(plane) + self.r0 * self.base.w * 16
+
+    def lo_ptr(self, plane: int = 0) -> int | None:
+        p = self.base.lo_ptr(plane)
+        return None if p is None else p + self.r0 * self.base.w * 16
+
+
 def empty_f32map(n: int, channels: int, h: int, w: int, device) -> torch.Tensor:
     return torch.empty((n, (channels + 3) // 4, h, w, 4), dtype=torch.float32, device=device)
 

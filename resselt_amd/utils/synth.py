@@ -78,6 +78,38 @@ def rrdbnet_state_dict(in_nc=3, out_nc=3, nf=64, nb=23, gc=32, scale=4, plus=Fal
     return out
 
 
+def rrdbnet_heavy_tailed_state_dict(nb=23, nf=64, gc=32, seed=0, df=3.0, outlier_gain=32.0, outlier_every=5) -> 'OrderedDict[str, torch.Tensor]':
+    """RRDBNet checkpoint with the statistics uniform synthetic weights lack: heavy-tailed weights and outlier activation channels.
+
+    * every weight tensor is re-drawn from a Student-t (``df`` degrees of freedom) scaled to the variance of the default uniform
+      init, so single weights reach 10-30x the typical magnitude;
+    * inside every RDB, every ``outlier_every``-th growth channel of x1..x4 is scaled by ``outlier_gain`` at its producer (weight row
+      and bias) and by ``1 / outlier_gain`` at every consumer (weight column).  LeakyReLU is positively homogeneous, so the network
+      function is unchanged, but those channels carry activations ``outlier_gain`` times larger than their neighbours -- the
+      situation in which a hi/lo operand split and an f32 accumulator are stressed.
+    """
+    sd = rrdbnet_state_dict(nf=nf, nb=nb, gc=gc, seed=seed)
+    for name in list(sd):
+        t = sd[name]
+        fan_in = t[0].numel() if name.endswith('.weight') else sd[name[: -len('bias')] + 'weight'][0].numel()
+        rng = np.random.Generator(np.random.PCG64([zlib.crc32(name.encode()), seed, 0x7A11]))
+        a = rng.standard_t(df, size=tuple(t.shape)).astype(np.float32)
+        a *= float(np.sqrt(1.0 / (3.0 * fan_in)) / np.sqrt(df / (df - 2.0)))  # variance of uniform(+-1/sqrt(fan_in)) = 1 / (3 fan_in)
+        sd[name] = torch.from_numpy(a)
+    g = float(outlier_gain)
+    for i in range(nb):
+        for r in (1, 2, 3):
+            p = f'model.1.sub.{i}.RDB{r}'
+            for j in range(1, 5):
+                chans = list(range((i + r + j) % outlier_every, gc, outlier_every))
+                sd[f'{p}.conv{j}.0.weight'][chans] *= g
+                sd[f'{p}.conv{j}.0.bias'][chans] *= g
+                cols = [nf + (j - 1) * gc + c for c in chans]
+                for m in range(j + 1, 6):
+                    sd[f'{p}.conv{m}.0.weight'][:, cols] /= g
+    return sd
+
+
 def _conv3xc(sd, name, cout, cin, gain, seed):
     _conv(sd, f'{name}.sk', cout, cin, 1, seed)
     _conv(sd, f'{name}.conv.0', cin * gain, cin, 1, seed)

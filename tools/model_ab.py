@@ -29,6 +29,8 @@ for a in sys.argv[1:]:
     kv = dict(t.split(':') for t in spec.split(','))
     m = resselt_amd.load_from_state_dict(dict(sd)).to(dev)
     m.plane_residuals = bool(int(kv.get('plane_residuals', 1)))
+    if 'tail_band_rows' in kv:
+        m.tail_band_rows = int(kv['tail_band_rows'])
     lib.rsa_debug_set_ring(int(kv.get('ring', 1)))
     y = m(x)  # builds the plan (descriptors carry the schedule)
     torch.cuda.synchronize()

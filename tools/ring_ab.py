@@ -34,6 +34,13 @@ for cfg in configs:
     x = tensors.Planes.empty(1, cin // 8, H // 2 if up else H, W // 2 if up else W, dev)
     x.hi.copy_(torch.randn(x.hi.shape, device=dev).to(torch.bfloat16))
     x.lo.copy_((torch.randn(x.lo.shape, device=dev) * 0.004).to(torch.bfloat16))
+    mode = os.environ.get('AB_DATA', 'random')  # operand-data experiments (power): zero, lozero, lo4 (lo keeps 4 significant bits)
+    if mode == 'zero':
+        x.hi.zero_(), x.lo.zero_()
+    elif mode == 'lozero':
+        x.lo.zero_()
+    elif mode == 'lo4':
+        x.lo.copy_((x.lo.view(torch.int16) & -16).view(torch.bfloat16))
     out = tensors.Planes.empty(1, (cout + 7) // 8, H, W, dev)
     descs = {}
     for name, mode in (('ring', 1), ('old', 0)):
