@@ -53,8 +53,11 @@ enum rsa_act {
   RSA_ACT_PRELU = 6      /* per-channel slopes act_vec[cout]; nn.PReLU(num_parameters=C), compact/arch.py:42-52 */
 };
 
-/* dtype of plain NCHW tensors crossing the boundary */
-enum rsa_dtype { RSA_F32 = 0, RSA_F16 = 1, RSA_BF16 = 2 };
+/* dtype of plain tensors crossing the boundary.  F32 / F16 / BF16: NCHW float tensors.  RSA_U8: an 8-bit IMAGE, channel-interleaved
+ * [N][H][W][C] as image decoders deliver it (the reference leaves both conversions to its callers):
+ *   read  (rsa_nchw_to_planes):           v = byte / 255   (a true division: bit-identical to torch's img.float() / 255)
+ *   write (rsa_conv2d final store):       byte = round-half-even(clamp(v, 0, 1) * 255)   (torch: (y.clamp(0, 1) * 255).round()) */
+enum rsa_dtype { RSA_F32 = 0, RSA_F16 = 1, RSA_BF16 = 2, RSA_U8 = 3 };
 
 /*
  * One fused convolution launch.
@@ -106,8 +109,8 @@ typedef struct rsa_conv_params {
   int64_t out_batch_stride; /* units */
   float* out_f32;           /* f32 NCHW4c residual stream */
 
-  void* out_nchw;           /* final plain tensor [N][cout/r^2][H*r][W*r], dtype out_dtype; exclusive with
-                               out_hi/out_f32/res1/res2 (separate kernel instantiation) */
+  void* out_nchw;           /* final plain tensor [N][cout/r^2][H*r][W*r], dtype out_dtype -- or, for RSA_U8, the 8-bit image
+                               [N][H*r][W*r][cout/r^2]; exclusive with out_hi/out_f32/res1/res2 (separate kernel instantiation) */
   int32_t out_dtype;        /* enum rsa_dtype */
   int32_t pixel_shuffle;    /* r >= 1 (depth-to-space factor applied while storing out_nchw) */
   float out_scale;          /* out_nchw value = v * out_scale + out_shift[oc]  (SwinIR x/img_range + mean, */
@@ -288,6 +291,10 @@ typedef struct rsa_rect_attn_params {
    * [heads][QT][KT][64][16] with QT = ceil(win_h*win_w / 32), KT = ceil(kwin_h*kwin_w / 32).  No shift, Hp == H, Wp == W. */
   int32_t kwin_h, kwin_w;
   int32_t kpad_h, kpad_w;
+  /* Wide heads: a head slot is head_chunks x 4 planes (head_dim <= 32*head_chunks, zero-padded), 0 or 1 = the 32-channel slots above;
+   * 2..4 (self-attention only): DRCT's dense groups run heads of 46..122 channels (reference archs/drct/arch.py:204-329).  q planes
+   * [0, 4*head_chunks*heads_total), then k, then v; out planes [(head0 + h)*4*head_chunks, +4*head_chunks). */
+  int32_t head_chunks;
 } rsa_rect_attn_params;
 int rsa_rect_attention(const rsa_rect_attn_params* p, void* stream);
 

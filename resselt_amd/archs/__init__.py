@@ -8,6 +8,7 @@ this build registers the families of the hot path: ESRGAN/RRDBNe
 from ..registry import Registry
 from .compact import CompactArch
 from .dat import DatArch
+from .drct import DRCTArch
 from .esrgan import ESRGANArch
 from .hat import HATArch
 from .rtmosr import RTMoSRArch
@@ -18,5 +19,5 @@ from .swinir import SwinIRArch
 
 internal_registry = Registry()
 # relative order follows the reference's registry walk (tests/golden/registry_claims.npz): ESRGAN, HAT, dat, Compact, RTMoSR, spanplus, SwinIR, SpanPP, ..., SPAN
-for _arch in (ESRGANArch, HATArch, DatArch, CompactArch, RTMoSRArch, SpanPlusArch, SwinIRArch, SpanPPArch, SPANArch):
+for _arch in (ESRGANArch, HATArch, DatArch, CompactArch, RTMoSRArch, SpanPlusArch, SwinIRArch, SpanPPArch, DRCTArch, SPANArch):
     internal_registry.add(_arch())

@@ -1,0 +1,328 @@
+"""DRCT (Dense-residual-connected Transformer) on the MI355X engine -- drop-in for ``resselt/archs/drct/arch.py:617-792``.
+
+Reference structure: conv_first -> [patch_embed.norm] -> RDG x num_layers -> norm -> conv_after_body (+ conv_first) ->
+conv_before_upsample -> Upsample (conv + PixelShuffle) -> conv_last.  A dense group (RDG, arch.py:204-329) is five Swin blocks over a
+growing channel concatenation -- widths dim, dim+gc, ..., dim+4gc, with ``num_heads - width % num_heads`` heads, i.e. head widths of
+30..122 channels for the published dim 180 / gc 32 / 6 heads -- each followed by a 1x1 'adjust' convolution, and ``x5 * 0.2 + x``.
+
+On the engine:
+  * the concatenation ``torch.cat((x, x1, ..), -1)`` is ONE f32 token map of dim + 4gc channels: channel groups of 4 are the unit of
+    that layout, dim and gc are multiples of 4, so every adjust convolution stores its gc channels at a group offset and a block of
+    width w reads the first w channels (LayerNorm, residual) -- no copy.  (That addressing holds for one image per call.)
+  * a Swin block is LayerNorm -> qkv (k1) -> rsa_rect_attention with 16x16 windows and ``head_chunks`` = ceil(head_dim / 32) chunks of
+    32 channels per head (csrc/dat.hip, wide-head kernel) -> proj (+ shortcut) -> LayerNorm -> fc1 (GELU) -> fc2 (+ shortcut), all Linear
+    layers as k1 launches of the convolution kernels; the shift mask is index arithmetic on the actual (padded) size.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from ...engine import lib as L
+from ...engine import ops
+from ...engine.base import EngineModule, Plan
+from ...engine.paramtree import build_param_tree
+from ..dat.arch import bias_fragments
+from ..swinir.arch import relative_position_index, shift_attn_mask
+
+RGB_MEAN = (0.4488, 0.4371, 0.4040)  # arch.py:649
+
+
+def block_dims(embed_dim: int, gc: int, num_heads: int):
+    """(width, heads, shifted, mlp uses mlp_ratio) of the five Swin blocks of a dense group (arch.py:225-298)."""
+    out = []
+    for j in range(5):
+        dim = embed_dim + j * gc
+        heads = num_heads if j == 0 else num_heads - (dim % num_heads)
+        out.append((dim, heads, j in (1, 3), j < 3))
+    return out
+
+
+def regroup_qkv_wide(w: torch.Tensor, b: torch.Tensor | None, heads: int, pad: int) -> tuple[torch.Tensor, torch.Tensor]:
+    """[3C, C] -> [3*heads*pad, C]: row (which, head, d) <- which*C + head*hd + d, zero rows for d >= hd; q rows scaled by hd^-0.5."""
+    c3, c = w.shape
+    hd = c // heads
+    wn = torch.zeros((3, heads, pad, c), dtype=torch.float32, device=w.device)
+    bn = torch.zeros((3, heads, pad), dtype=torch.float32, device=w.device)
+    wn[:, :, :hd] = w.to(torch.float32).reshape(3, heads, hd, c)
+    if b is not None:
+        bn[:, :, :hd] = b.to(torch.float32).reshape(3, heads, hd)
+    wn[0] *= hd**-0.5
+    bn[0] *= hd**-0.5
+    return wn.reshape(3 * heads * pad, c), bn.reshape(-1)
+
+
+def regroup_proj_wide(w: torch.Tensor, heads: int, pad: int) -> torch.Tensor:
+    """[C, C] -> [C, heads*pad]: column (head, d) <- head*hd + d."""
+    c = w.shape[0]
+    hd = w.shape[1] // heads
+    wn = torch.zeros((c, heads, pad), dtype=torch.float32, device=w.device)
+    wn[:, :, :hd] = w.to(torch.float32).reshape(c, heads, hd)
+    return wn.reshape(c, heads * pad)
+
+
+def drct_param_shapes(in_chans, embed_dim, num_layers, num_heads, window, mlp_ratio, gc, upscale, resi, img_size, patch_norm, qkv_bias, upsampler):
+    shapes: dict = {}
+    buffers: dict = {}
+    C_ = embed_dim
+
+    def conv(name, co, ci, k):
+        shapes[f'{name}.weight'] = (co, ci, k, k)
+        shapes[f'{name}.bias'] = (co,)
+
+    def lin(name, co, ci, bias=True):
+        shapes[f'{name}.weight'] = (co, ci)
+        if bias:
+            shapes[f'{name}.bias'] = (co,)
+
+    def ln(name, c):
+        shapes[f'{name}.weight'] = (c,)
+        shapes[f'{name}.bias'] = (c,)
+
+    conv('conv_first', C_, in_chans, 3)
+    if patch_norm:
+        ln('patch_embed.norm', C_)
+    for i in range(num_layers):
+        for j, (dim, heads, shifted, full_mlp) in enumerate(block_dims(C_, gc, num_heads[i]), start=1):
+            b = f'layers.{i}.swin{j}'
+            hidden = int(dim * (mlp_ratio if full_mlp else 1))
+            ln(f'{b}.norm1', dim)
+            shapes[f'{b}.attn.relative_position_bias_table'] = ((2 * window - 1) ** 2, heads)
+            buffers[f'{b}.attn.relative_position_index'] = relative_position_index(window)
+            if shifted and img_size > window:
+                buffers[f'{b}.attn_mask'] = shift_attn_mask(img_size, window)
+            lin(f'{b}.attn.qkv', 3 * dim, dim, qkv_bias)
+            lin(f'{b}.attn.proj', dim, dim)
+            ln(f'{b}.norm2', dim)
+            lin(f'{b}.mlp.fc1', hidden, dim)
+            lin(f'{b}.mlp.fc2', dim, hidden)
+            conv(f'layers.{i}.adjust{j}', gc if j < 5 else C_, dim, 1)
+    ln('norm', C_)
+    if resi == '1conv':
+        conv('conv_after_body', C_, C_, 3)
+    if upsampler == 'pixelshuffle':
+        conv('conv_before_upsample.0', 64, C_, 3)
+        if upscale == 3:
+            conv('upsample.0', 9 * 64, 64, 3)
+        elif upscale & (upscale - 1) == 0:
+            for u in range(int(math.log2(upscale))):
+                conv(f'upsample.{2 * u}', 4 * 64, 64, 3)
+        else:
+            raise ValueError(f'scale {upscale} is not supported. Supported scales: 2^n and 3.')
+        conv('conv_last', in_chans, 64, 3)
+    return shapes, buffers
+
+
+class DRCT(EngineModule):
+    hyperparameters = {}
+
+    def __init__(self, *, img_size=64, patch_size=1, in_chans=3, embed_dim=180, depths=(6, 6, 6, 6, 6, 6), num_heads=(6, 6, 6, 6, 6, 6),
+                 window_size=16, mlp_ratio=2.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1,
+                 ape=False, patch_norm=True, upscale=1, img_range=1.0, upsampler='', resi_connection='1conv', gc=32) -> None:  # fmt: skip
+        super().__init__()
+        if patch_size != 1 or ape or qk_scale is not None:
+            raise NotImplementedError('DRCT engine supports patch_size=1, ape=False, default qk scale (what the loader builds)')
+        if upsampler != 'pixelshuffle':
+            raise NotImplementedError("DRCT reconstructs only with upsampler='pixelshuffle' (the reference forward returns its input otherwise)")
+        if embed_dim % 4 or gc % 4:
+            raise NotImplementedError('embed_dim and gc must be multiples of 4 (channel groups of the f32 token map)')
+        if window_size * window_size > 256:
+            raise NotImplementedError('window must hold at most 256 tokens')
+        if img_size <= window_size:
+            raise NotImplementedError('img_size <= window_size changes the block geometry; not supported')
+        num_heads = list(num_heads)
+        for nh in num_heads:
+            for dim, heads, _, _ in block_dims(embed_dim, gc, nh):
+                if heads < 1 or dim % heads or dim // heads > 128:
+                    raise NotImplementedError(f'block width {dim} with {heads} heads: head_dim must divide the width and be <= 128')
+        self.in_chans, self.embed_dim, self.num_heads, self.num_layers = in_chans, embed_dim, num_heads, len(num_heads)
+        self.window_size, self.mlp_ratio, self.gc = window_size, mlp_ratio, gc
+        self.upscale, self.img_range, self.resi, self.patch_norm, self.qkv_bias = upscale, img_range, resi_connection, patch_norm, qkv_bias
+        shapes, buffers = drct_param_shapes(in_chans, embed_dim, self.num_layers, num_heads, window_size, mlp_ratio, gc, upscale, resi_connection,
+                                            img_size, patch_norm, qkv_bias, upsampler)  # fmt: skip
+        build_param_tree(self, shapes, buffers)
+
+    # ---------------------------------------------------------------- weights
+    def _pack(self, device, products):
+        sd = {k: v.detach().to(device) for k, v in self.state_dict().items()}
+        W: dict = {}
+
+        def conv(name):
+            W[name] = ops.ConvWeights.from_oihw(sd[f'{name}.weight'], sd.get(f'{name}.bias'), products, device=device)
+
+        def lin(name, w=None, b=None, cin_planes=None):
+            w = sd[f'{name}.weight'] if w is None else w
+            b = sd.get(f'{name}.bias') if b is None else b
+            W[name] = ops.ConvWeights.from_oihw(w[:, :, None, None], b, products, cin_planes=cin_planes, device=device)
+
+        def ln(name):
+            W[name] = (sd[f'{name}.weight'].float().contiguous(), sd[f'{name}.bias'].float().contiguous())
+
+        conv('conv_first')
+        if self.patch_norm:
+            ln('patch_embed.norm')
+        win = self.window_size
+        for i in range(self.num_layers):
+            for j, (dim, heads, _, _) in enumerate(block_dims(self.embed_dim, self.gc, self.num_heads[i]), start=1):
+                b = f'layers.{i}.swin{j}'
+                pad = 32 * -(-(dim // heads) // 32)
+                ln(f'{b}.norm1')
+                ln(f'{b}.norm2')
+                wq, bq = regroup_qkv_wide(sd[f'{b}.attn.qkv.weight'], sd.get(f'{b}.attn.qkv.bias'), heads, pad)
+                lin(f'{b}.attn.qkv', wq, bq)
+                lin(f'{b}.attn.proj', regroup_proj_wide(sd[f'{b}.attn.proj.weight'], heads, pad), sd[f'{b}.attn.proj.bias'], cin_planes=heads * pad // 8)
+                lin(f'{b}.mlp.fc1')
+                lin(f'{b}.mlp.fc2')
+                n = win * win
+                dense = sd[f'{b}.attn.relative_position_bias_table'].float()[sd[f'{b}.attn.relative_position_index'].reshape(-1).long()]
+                W[f'{b}.bias_frag'] = bias_fragments(dense.reshape(n, n, heads).permute(2, 0, 1).contiguous())
+                conv(f'layers.{i}.adjust{j}')
+        ln('norm')
+        for name in ('conv_after_body', 'conv_before_upsample.0', 'upsample.0', 'upsample.2', 'upsample.4', 'conv_last'):
+            if f'{name}.weight' in sd:
+                conv(name)
+        W['mean'] = torch.tensor(RGB_MEAN if self.in_chans == 3 else [0.0] * self.in_chans, dtype=torch.float32, device=device)
+        return W
+
+    # ---------------------------------------------------------------- plan
+    def _build_plan(self, plan: Plan, W, x_shape, dtype, products):
+        n, c, h0, w0 = x_shape
+        if c != self.in_chans:
+            raise RuntimeError(f'model expects {self.in_chans} input channels, got {c}')
+        if n != 1:
+            raise NotImplementedError('the DRCT engine runs one image per call (the dense concatenation is addressed by channel-group offsets)')
+        win = self.window_size
+        H, Wd = h0 + (win - h0 % win) % win, w0 + (win - w0 % win) % win
+        if H - h0 >= h0 or Wd - w0 >= w0:
+            raise RuntimeError('input is too small for reflect padding to a multiple of the window size')
+        C_, gc, s = self.embed_dim, self.gc, self.upscale
+        wide = C_ + 4 * gc
+        with_lo = products == 3
+        dev = plan.device
+        lib = L.load()
+        HW = H * Wd
+
+        x_pl = plan.planes(n, (c + 7) // 8, H, Wd, with_lo)
+        mean = W['mean']
+
+        def set_input(x):
+            # (x - mean) * img_range and check_img_size's reflect padding (arch.py:765-776), fused into the layout kernel
+            ops.nchw_to_planes(x, x_pl, mean, self.img_range)
+
+        first = plan.f32map(n, C_, H, Wd)
+        cat = [plan.f32map(n, wide, H, Wd) for _ in range(2)]  # dense concatenation of a group: x | x1 | x2 | x3 | x4
+        blk = [plan.f32map(n, wide, H, Wd) for _ in range(2)]  # a Swin block's two residual sums
+        max_pad = max(heads * 32 * -(-(dim // heads) // 32) for nh in self.num_heads for dim, heads, _, _ in block_dims(C_, gc, nh))
+        a_pl = plan.planes(n, (wide + 7) // 8, H, Wd, with_lo)
+        qkv_pl = plan.planes(n, 3 * max_pad // 8, H, Wd, with_lo)
+        o_pl = plan.planes(n, max_pad // 8, H, Wd, with_lo)
+        hid_pl = plan.planes(n, (int(wide * max(self.mlp_ratio, 1.0)) + 7) // 8, H, Wd, with_lo)
+        t_pl = plan.planes(n, (wide + 7) // 8, H, Wd, with_lo)  # a block's output as planes (input of its adjust convolution)
+        body_pl = plan.planes(n, (C_ + 7) // 8, H, Wd, with_lo)
+
+        def chan_view(m: torch.Tensor, c0: int, cn: int) -> torch.Tensor:
+            """Channels [c0, c0 + cn) of an f32 token map as a map of their own (one image: groups are contiguous)."""
+            return m[:, c0 // 4 : (c0 + cn) // 4]
+
+        def layernorm(name, x_f32, C_in, out_planes=None, out_f32=None):
+            g, b = W[name]
+            lp = L.LayerNormParams()
+            lp.batch, lp.H, lp.W, lp.C, lp.eps = n, H, Wd, C_in, 1e-5
+            lp.x_f32, lp.gamma, lp.beta = x_f32.data_ptr(), g.data_ptr(), b.data_ptr()
+            if out_planes is not None:
+                lp.out_hi, lp.out_lo = out_planes.hi_ptr(), out_planes.lo_ptr()
+                lp.out_plane_stride, lp.out_batch_stride = out_planes.plane_stride, out_planes.batch_stride
+            lp.out_f32 = None if out_f32 is None else out_f32.data_ptr()
+            plan.call(lambda: L.check(lib.rsa_layernorm(C.byref(lp), C.c_void_p(ops.current_stream_ptr(dev))), 'rsa_layernorm'))
+            plan.count_launches(1)
+
+        def attention(name, heads, chunks, shifted):
+            ap = L.RectAttnParams()
+            ap.batch, ap.H, ap.W, ap.Hp, ap.Wp = n, H, Wd, H, Wd
+            ap.win_h = ap.win_w = win
+            ap.shift_h = ap.shift_w = win // 2 if shifted else 0
+            ap.heads, ap.head0, ap.heads_total, ap.products, ap.head_chunks = heads, 0, heads, products, chunks
+            ap.qkv_hi, ap.qkv_lo, ap.qkv_plane_stride, ap.qkv_batch_stride = qkv_pl.hi_ptr(), qkv_pl.lo_ptr(), qkv_pl.plane_stride, qkv_pl.batch_stride
+            ap.bias_frag = W[f'{name}.bias_frag'].data_ptr()
+            ap.out_hi, ap.out_lo, ap.out_plane_stride, ap.out_batch_stride = o_pl.hi_ptr(), o_pl.lo_ptr(), o_pl.plane_stride, o_pl.batch_stride
+            plan.call(lambda: L.check(lib.rsa_rect_attention(C.byref(ap), C.c_void_p(ops.current_stream_ptr(dev))), 'rsa_rect_attention'))
+            plan.count_launches(1)
+
+        def f32_view_conv(wts, src, **kw):
+            """conv_params with f32 operands that are channel views of wider maps: checked against the view, passed by pointer."""
+            return ops.conv_params(wts, src, H, Wd, **kw)
+
+        plan.conv(ops.conv_params(W['conv_first'], x_pl, H, Wd, out_f32=first))
+        cur = cat[0]
+        if self.patch_norm:
+            layernorm('patch_embed.norm', first, C_, out_f32=chan_view(cur, 0, C_))
+        else:
+            plan.call(lambda dst=chan_view(cur, 0, C_): dst.copy_(first))
+        ci = 0
+        for i in range(self.num_layers):
+            cur, nxt = cat[ci], cat[ci ^ 1]
+            for j, (dim, heads, shifted, full_mlp) in enumerate(block_dims(C_, gc, self.num_heads[i]), start=1):
+                b = f'layers.{i}.swin{j}'
+                chunks = -(-(dim // heads) // 32)
+                hp = heads * 32 * chunks // 8
+                cp = (dim + 7) // 8
+                hidden = int(dim * (self.mlp_ratio if full_mlp else 1))
+                xin = chan_view(cur, 0, dim)
+                layernorm(f'{b}.norm1', xin, dim, out_planes=a_pl)
+                plan.conv(ops.conv_params(W[f'{b}.attn.qkv'], a_pl, H, Wd, cin_planes=cp, out=qkv_pl))
+                attention(b, heads, chunks, shifted)
+                x1 = chan_view(blk[0], 0, dim)
+                plan.conv(f32_view_conv(W[f'{b}.attn.proj'], o_pl, cin_planes=hp, res1=xin, alpha=1.0, out_f32=x1))
+                layernorm(f'{b}.norm2', x1, dim, out_planes=a_pl)
+                plan.conv(ops.conv_params(W[f'{b}.mlp.fc1'], a_pl, H, Wd, cin_planes=cp, act=L.ACT_GELU, out=hid_pl))
+                plan.conv(f32_view_conv(W[f'{b}.mlp.fc2'], hid_pl, cin_planes=(hidden + 7) // 8, res1=x1, alpha=1.0, out=t_pl))
+                # adjust_j (1x1) on the block's output: x_j = lrelu(.) stored at channel offset dim of the concatenation;
+                # adjust_5 closes the group: x5 * 0.2 + x into the first C_ channels of the next group's concatenation
+                if j < 5:
+                    plan.conv(f32_view_conv(W[f'layers.{i}.adjust{j}'], t_pl, cin_planes=cp, act=L.ACT_LRELU, act_param=0.2, out_f32=chan_view(cur, dim, gc)))
+                else:
+                    plan.conv(f32_view_conv(W[f'layers.{i}.adjust{j}'], t_pl, cin_planes=cp, res1=chan_view(cur, 0, C_), alpha=0.2, out_f32=chan_view(nxt, 0, C_)))
+            ci ^= 1
+        cur = cat[ci]
+        layernorm('norm', chan_view(cur, 0, C_), C_, out_planes=a_pl)
+        cp0 = (C_ + 7) // 8
+        if self.resi == '1conv':
+            plan.conv(ops.conv_params(W['conv_after_body'], a_pl, H, Wd, cin_planes=cp0, res1=first, alpha=1.0, out=body_pl))
+        else:
+            raise NotImplementedError("resi_connection='identity' (norm output + conv_first as planes) is not built")
+
+        out_shape = (n, self.in_chans, H * s, Wd * s)
+        out_buf = {'y': torch.empty(out_shape, dtype=dtype, device=dev)}
+        final = dict(out_scale=1.0 / self.img_range, out_shift=mean)  # x / img_range + mean (arch.py:790)
+        y = plan.planes(n, 8, H, Wd, with_lo)
+        plan.conv(ops.conv_params(W['conv_before_upsample.0'], body_pl, H, Wd, cin_planes=cp0, act=L.ACT_LRELU, act_param=0.01, out=y))
+        hh, ww = H, Wd
+        i = 0
+        while f'upsample.{i}' in W:
+            r = math.isqrt(W[f'upsample.{i}'].cout // 64)
+            shuffled = torch.empty((n, 64, hh * r, ww * r), dtype=torch.float32, device=dev)
+            plan.keep.append(shuffled)
+            plan.conv(ops.conv_params(W[f'upsample.{i}'], y, hh, ww, out_nchw=shuffled, pixel_shuffle=r))
+            hh, ww = hh * r, ww * r
+            ny = plan.planes(n, 8, hh, ww, with_lo)
+            plan.call(lambda src=shuffled, dst=ny: ops.nchw_to_planes(src, dst))
+            y = ny
+            i += 2
+        plan.conv(ops.conv_params(W['conv_last'], y, hh, ww, out_nchw=out_buf['y'], **final))
+        arr = plan.flush()
+        last_entry = arr[len(arr) - 1]
+
+        def prepare_output():
+            if 'y' not in out_buf:
+                out_buf['y'] = torch.empty(out_shape, dtype=dtype, device=dev)
+            last_entry.out_nchw = out_buf['y'].data_ptr()
+
+        plan.steps.insert(len(plan.steps) - 1, prepare_output)
+
+        def get_output():
+            return out_buf.pop('y')[:, :, : h0 * s, : w0 * s]
+
+        return set_input, get_output

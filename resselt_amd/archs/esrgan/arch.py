@@ -88,6 +88,7 @@ def new_arch_to_old(state_dict) -> dict:
 
 class RRDBNet(EngineModule):
     hyperparameters = {}
+    supports_u8 = True  # uint8 [N, H, W, C] images: /255 in the layout kernel, clamp*255+round in the last convolution's store
 
     def __init__(self, in_nc: int = 3, out_nc: int = 3, num_filters: int = 64, num_blocks: int = 23, scale: int = 4,
                  plus: bool = False, shuffle_factor: int | None = None) -> None:  # fmt: skip
@@ -229,6 +230,8 @@ class RRDBNet(EngineModule):
         hr_buf = plan.planes(n, pf, sub_h * s_net, w * s_net, with_lo)
         hh, wwid = h * s_net, w * s_net
         out_buf: dict = {}
+        u8 = dtype == torch.uint8
+        out_shape = (n, hh, wwid, self.out_nc) if u8 else (n, self.out_nc, hh, wwid)
         band_out = torch.empty(n * self.out_nc * sub_h * s_net * wwid, dtype=dtype, device=plan.device) if n_bands > 1 else None  # flat: each band views it densely
         plan.keep.append(band_out)
         from ...engine.tensors import PlaneRows
@@ -250,17 +253,21 @@ class RRDBNet(EngineModule):
             hr = PlaneRows(hr_buf, 0, rows * s_net) if n_bands > 1 else hr_buf
             plan.conv(ops.conv_params(W[f'model.{k}'], src, rows * s_net, wwid, out=hr, **lrelu))
             if n_bands > 1:
-                tmp = band_out[: n * self.out_nc * rows * s_net * wwid].view(n, self.out_nc, rows * s_net, wwid)
+                tmp = band_out[: n * self.out_nc * rows * s_net * wwid]
+                tmp = tmp.view(n, rows * s_net, wwid, self.out_nc) if u8 else tmp.view(n, self.out_nc, rows * s_net, wwid)
                 plan.conv(ops.conv_params(W[f'model.{k + 2}'], hr, rows * s_net, wwid, out_nchw=tmp))
                 arr = plan.flush()
                 lo, hi_ = (a0 - r0) * s_net, (a1 - r0) * s_net
 
                 def copy_band(tmp=tmp, lo=lo, hi_=hi_, y0=a0 * s_net, y1=a1 * s_net):
-                    out_buf['y'][:, :, y0:y1] = tmp[:, :, lo:hi_]
+                    if u8:
+                        out_buf['y'][:, y0:y1] = tmp[:, lo:hi_]
+                    else:
+                        out_buf['y'][:, :, y0:y1] = tmp[:, :, lo:hi_]
 
                 plan.call(copy_band)
             else:
-                placeholder = torch.empty((n, self.out_nc, hh, wwid), dtype=dtype, device=plan.device)
+                placeholder = torch.empty(out_shape, dtype=dtype, device=plan.device)
                 out_buf['y'] = placeholder
                 plan.conv(ops.conv_params(W[f'model.{k + 2}'], hr, hh, wwid, out_nchw=placeholder))
                 arr = plan.flush()
@@ -269,7 +276,7 @@ class RRDBNet(EngineModule):
         # a fresh output tensor per call (single band: patch the last descriptor's pointer; bands: the copies fill it)
         def prepare_output():
             if 'y' not in out_buf:
-                out_buf['y'] = torch.empty((n, self.out_nc, hh, wwid), dtype=dtype, device=plan.device)
+                out_buf['y'] = torch.empty(out_shape, dtype=dtype, device=plan.device)
             for e in last_entries:
                 e.out_nchw = out_buf['y'].data_ptr()
 
@@ -280,7 +287,7 @@ class RRDBNet(EngineModule):
         def get_output():
             y = out_buf.pop('y')
             if sf:
-                y = y[:, :, : h_in * self.scale, : w_in * self.scale]
+                y = y[:, : h_in * self.scale, : w_in * self.scale] if u8 else y[:, :, : h_in * self.scale, : w_in * self.scale]
             return y
 
         return set_input, get_output

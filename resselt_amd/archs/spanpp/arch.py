@@ -133,7 +133,8 @@ class SpanPP(EngineModule):
             raise KeyError(str(s))  # the reference's eval_convs lookup raises the same for a scale outside scale_list
         if s != self._scale:
             self._scale = s
-            self._plans = {}
+            for key in list(self._plans):
+                self._drop_plan(key)
         return super().forward(x)
 
     def _build_plan(self, plan: Plan, W, x_shape, dtype, products):

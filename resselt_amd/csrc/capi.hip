@@ -59,7 +59,9 @@ __global__ void nchw_to_planes_kernel(const void* x, int dtype, int batch, int C
         if (sy >= srcH) sy = 2 * (srcH - 1) - sy;
         if (sx >= srcW) sx = 2 * (srcW - 1) - sx;
         const int64_t src = ((int64_t)n * C + c) * sHW + (int64_t)sy * srcW + sx;
-        if (dtype == RSA_F32)
+        if (dtype == RSA_U8)  // 8-bit image, channel-interleaved [N][srcH][srcW][C]
+          v = (float)((const uint8_t*)x)[(((int64_t)n * srcH + sy) * srcW + sx) * C + c] / 255.f;
+        else if (dtype == RSA_F32)
           v = ld_as_float<float>(x, src);
         else if (dtype == RSA_F16)
           v = ld_as_float<_Float16>(x, src);
@@ -198,7 +200,7 @@ int rsa_nchw_to_planes(const void* x, int32_t dtype, int32_t batch, int32_t C, i
     if (src_h < 1 || src_w < 1 || src_h > fh || src_w > fw || fh - src_h >= src_h || fw - src_w >= src_w)
       return rsa::set_error(RSA_E_ARG, "nchw_to_planes: source size must satisfy src <= plane size * unshuffle < 2*src (reflect padding)");
   }
-  if (dtype < RSA_F32 || dtype > RSA_BF16) return rsa::set_error(RSA_E_ARG, "nchw_to_planes: bad dtype");
+  if (dtype < RSA_F32 || dtype > RSA_U8) return rsa::set_error(RSA_E_ARG, "nchw_to_planes: bad dtype");
   if (((uintptr_t)out_hi | (uintptr_t)out_lo) & 15) return rsa::set_error(RSA_E_ALIGN, "nchw_to_planes: outputs must be 16-byte aligned");
   const int64_t total = (int64_t)batch * ((C * unshuffle * unshuffle + 7) / 8) * H * W;
   hipLaunchKernelGGL(rsa::nchw_to_planes_kernel, dim3(rsa::grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, dtype, batch, C, H, W,

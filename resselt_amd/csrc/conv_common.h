@@ -339,7 +339,10 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
                 o += (float)((const __bf16*)p.out_base)[bi];
             }
             const int64_t idx = ((int64_t)n * oc_total + oc) * oHW + ((int64_t)y * ps + ii) * oW + ((int64_t)x * ps + jj);
-            if (p.out_dtype == RSA_F32)
+            if (p.out_dtype == RSA_U8) {  // 8-bit image, channel-interleaved: clamp, scale, round half to even (v_rndne)
+              const int64_t pidx = (((int64_t)n * p.H * ps + ((int64_t)y * ps + ii)) * oW + ((int64_t)x * ps + jj)) * oc_total + oc;
+              ((uint8_t*)p.out_nchw)[pidx] = (uint8_t)rintf(fminf(fmaxf(o, 0.f), 1.f) * 255.f);
+            } else if (p.out_dtype == RSA_F32)
               ((float*)p.out_nchw)[idx] = o;
             else if (p.out_dtype == RSA_F16)
               ((_Float16*)p.out_nchw)[idx] = (_Float16)o;

@@ -76,7 +76,8 @@ int conv_launch(const rsa_conv_params& p, hipStream_t stream) {
       return set_error(RSA_E_UNSUPPORTED, "conv: out_nchw is a final store: no plane/f32 outputs or residuals with it");
     const int ps = p.pixel_shuffle > 1 ? p.pixel_shuffle : 1;
     if (p.cout % (ps * ps) != 0) return set_error(RSA_E_ARG, "conv: cout not divisible by pixel_shuffle^2");
-    if (p.out_dtype < RSA_F32 || p.out_dtype > RSA_BF16) return set_error(RSA_E_ARG, "conv: bad out_dtype");
+    if (p.out_dtype < RSA_F32 || p.out_dtype > RSA_U8) return set_error(RSA_E_ARG, "conv: bad out_dtype");
+    if (p.out_dtype == RSA_U8 && p.out_base != nullptr) return set_error(RSA_E_UNSUPPORTED, "conv: an 8-bit image store takes no base image");
   }
   if (p.w_layout != RSA_WL_TAPS && p.w_layout != RSA_WL_PAIRS) return set_error(RSA_E_ARG, "conv: unknown w_layout");
   if (p.w_layout == RSA_WL_PAIRS) {  // ring schedule (conv_ring.h): the descriptor carries the K order its weights were packed in

@@ -300,6 +300,234 @@ __global__ __launch_bounds__(256, 2) void rect_attention_kernel(const rsa_rect_a
   }
 }
 
+// ------------------------------------------------------------------------------------------------ wide-head window attention
+// Self-attention of a (shifted) window whose heads are wider than 32 channels: head_dim <= 32*DC, DC = 2..4 (DRCT's dense groups run
+// 2-6 heads of 46..122 channels over 16x16 windows: reference archs/drct/arch.py:102-198, 204-329).  A head slot is DC "chunks" of 4
+// planes.  Same mathematics and fragment orders as rect_attention_kernel; what changes is the staging: the K / V images of a whole
+// 256-token window no longer fit LDS at 128 channels, so keys are staged 64 at a time (two key tiles, all chunks) and the running
+// max / sum / output of a wave's query tile carry over the stages, flash style.  8 waves, wave w owns query tile w.
+template <int PROD, int DC>
+__global__ __launch_bounds__(512, 1) void rect_attention_wide_kernel(const rsa_rect_attn_params p, int TB) {
+  constexpr int TS = 2;          // key tiles per stage
+  constexpr int NK = 32 * TS;    // keys per stage
+  constexpr int KROW = 40;       // bf16 per K row of one chunk (80 bytes: conflict-free A-fragment reads)
+  constexpr int NHL = PROD == 3 ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) __bf16 s_k[NHL][DC][NK * KROW];
+  __shared__ __attribute__((aligned(16))) __bf16 s_v[NHL][DC][NK * 32];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntok = p.win_h * p.win_w;
+  const int QT = (ntok + 31) >> 5;
+  const int KT = QT;
+  const int nwx = p.Wp / p.win_w, nwy = p.Hp / p.win_h;
+  const int64_t item = blockIdx.x;
+  const int head = (int)(item % p.heads);
+  const int64_t win = item / p.heads;
+  const int wx = (int)(win % nwx);
+  const int wy = (int)((win / nwx) % nwy);
+  const int n = (int)(win / ((int64_t)nwx * nwy));
+
+  auto token_pix = [&](int t, bool& valid) -> int64_t {  // roll(-shift) on the padded grid, then partition; padding tokens are zero
+    const int ty = t / p.win_w, tx = t - ty * p.win_w;
+    int sy = wy * p.win_h + ty + p.shift_h;
+    int sx = wx * p.win_w + tx + p.shift_w;
+    if (sy >= p.Hp) sy -= p.Hp;
+    if (sx >= p.Wp) sx -= p.Wp;
+    valid = t < ntok && sy < p.H && sx < p.W;
+    return valid ? (int64_t)sy * p.W + sx : 0;
+  };
+  const bf16x8* qkv_hi = (const bf16x8*)p.qkv_hi + (int64_t)n * p.qkv_batch_stride;
+  const bf16x8* qkv_lo = (PROD == 3) ? (const bf16x8*)p.qkv_lo + (int64_t)n * p.qkv_batch_stride : nullptr;
+  const int64_t ps = p.qkv_plane_stride;
+  const int slot = p.head0 + head;
+  const int64_t q_plane0 = (int64_t)(0 * p.heads_total + slot) * 4 * DC;
+  const int64_t k_plane0 = (int64_t)(1 * p.heads_total + slot) * 4 * DC;
+  const int64_t v_plane0 = (int64_t)(2 * p.heads_total + slot) * 4 * DC;
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  const int lr = lane & 31;
+  const int lh = lane >> 5;
+  const int g16 = lane >> 4;
+  const int li16 = lane & 15;
+  const bool masked = p.shift_h > 0 && (wy == nwy - 1 || wx == nwx - 1);
+  auto region = [&](int t) -> int {
+    const int tt = t < ntok ? t : 0;
+    const int ty = tt / p.win_w, tx = tt - ty * p.win_w;
+    const int gy = wy * p.win_h + ty, gx = wx * p.win_w + tx;
+    const int ry = gy < p.Hp - p.win_h ? 0 : (gy < p.Hp - p.shift_h ? 1 : 2);
+    const int rx = gx < p.Wp - p.win_w ? 0 : (gx < p.Wp - p.shift_w ? 1 : 2);
+    return ry * 3 + rx;
+  };
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+  // ---- this wave's query tile: Q fragments of every chunk stay in registers for the whole window ----
+  const int qt = wave;
+  const bool qlive = qt < QT;
+  bool qvalid;
+  const int64_t qpix = token_pix(32 * qt + lr, qvalid);
+  if (!qlive) qvalid = false;
+  bf16x8 qh[DC][2], ql[DC][2];
+#pragma unroll
+  for (int c = 0; c < DC; ++c)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      qh[c][s] = zero8;
+      ql[c][s] = zero8;
+      if (qvalid) {
+        qh[c][s] = qkv_hi[(q_plane0 + 4 * c + 2 * s + lh) * ps + qpix];
+        if (PROD == 3) ql[c][s] = qkv_lo[(q_plane0 + 4 * c + 2 * s + lh) * ps + qpix];
+      }
+    }
+  const int rq = masked ? region(32 * qt + lr) : 0;
+  float m = -3.0e38f, l = 0.f;
+  f32x16 ot[DC];
+#pragma unroll
+  for (int c = 0; c < DC; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[c][r] = 0.f;
+
+  for (int kt0 = 0; kt0 < KT; kt0 += TS) {
+    if (kt0 > 0) __syncthreads();
+    // ---- stage keys [32*kt0, 32*kt0 + 64): thread = (key, plane group); 4*DC planes of K and of V each ----
+    {
+      const int key = tid & (NK - 1);
+      bool valid;
+      const int64_t pix = token_pix(32 * kt0 + key, valid);
+      for (int pl = tid / NK; pl < 4 * DC; pl += 512 / NK) {
+        const int c = pl >> 2, j = pl & 3;
+        bf16x8 kh = zero8, kl = zero8, vh = zero8, vl = zero8;
+        if (valid) {
+          kh = qkv_hi[(k_plane0 + pl) * ps + pix];
+          vh = qkv_hi[(v_plane0 + pl) * ps + pix];
+          if (PROD == 3) {
+            kl = qkv_lo[(k_plane0 + pl) * ps + pix];
+            vl = qkv_lo[(v_plane0 + pl) * ps + pix];
+          }
+        }
+        *(bf16x8*)&s_k[0][c][key * KROW + j * 8] = kh;
+        *(bf16x8*)&s_v[0][c][key * 32 + j * 8] = vh;
+        if (PROD == 3) {
+          *(bf16x8*)&s_k[NHL - 1][c][key * KROW + j * 8] = kl;
+          *(bf16x8*)&s_v[NHL - 1][c][key * 32 + j * 8] = vl;
+        }
+      }
+    }
+    __syncthreads();
+    if (!qlive) continue;  // (wave-uniform; the barriers above are reached by every wave)
+    const int ktn = (KT - kt0 < TS) ? KT - kt0 : TS;
+    for (int kt = 0; kt < ktn; ++kt) {
+      f32x16 a;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < DC; ++c)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int off = (32 * kt + lr) * KROW + (2 * s + lh) * 8;
+          const bf16x8 kh = *(const bf16x8*)&s_k[0][c][off];
+          if (PROD == 3) {
+            const bf16x8 kl = *(const bf16x8*)&s_k[NHL - 1][c][off];
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[c][s], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[c][s], a, 0, 0, 0);
+          }
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[c][s], a, 0, 0, 0);
+        }
+      const f32x4* bf = (const f32x4*)(p.bias_frag + ((((int64_t)head * TB + qt) * TB + kt0 + kt) * 64 + lane) * 16);
+      float tm = -3.0e38f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b = bf[g];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = g * 4 + e;
+          float v = a[r] + b[e];
+          if (masked) {
+            const int key = 32 * (kt0 + kt) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (region(key) != rq) v += -100.f;
+          }
+          a[r] = v;
+          tm = fmaxf(tm, v);
+        }
+      }
+      tm = fmaxf(tm, __shfl_xor(tm, 32));
+      const float mn = fmaxf(m, tm);
+      const float alpha = expf(m - mn);
+      m = mn;
+      l *= alpha;
+#pragma unroll
+      for (int c = 0; c < DC; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[c][r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = expf(a[r] - mn);
+        a[r] = e;
+        l += e;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float e8[8], r8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e8[j] = a[8 * s + j];
+        const bf16x8 ph = pack_bf16(e8);
+        bf16x8 pl8 = zero8;
+        if (PROD == 3) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) r8[j] = e8[j] - (float)ph[j];
+          pl8 = pack_bf16(r8);
+        }
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+          bf16x8 vh, vl;
+#pragma unroll
+          for (int g2 = 0; g2 < 2; ++g2) {
+            const int row = 32 * kt + 16 * s + 8 * g2 + 4 * lh + (li16 >> 2);
+            const int col = 16 * (g16 & 1) + 4 * (li16 & 3);
+            const bf16x4 th = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)&s_v[0][c][row * 32 + col]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vh[g2 * 4 + e] = th[e];
+            if (PROD == 3) {
+              const bf16x4 tl = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)&s_v[NHL - 1][c][row * 32 + col]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) vl[g2 * 4 + e] = tl[e];
+            }
+          }
+          if (PROD == 3) {
+            ot[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, ot[c], 0, 0, 0);
+            ot[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl8, ot[c], 0, 0, 0);
+          }
+          ot[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, ot[c], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- normalise and store: lane owns query 32qt + lr, channels (chunk c) 8g + 4lh .. +3 ----
+  const float lsum = l + __shfl_xor(l, 32);
+  if (!qvalid) return;
+  char* out_hi = (char*)p.out_hi + (int64_t)n * p.out_batch_stride * 16;
+  char* out_lo = (p.out_lo != nullptr) ? (char*)p.out_lo + (int64_t)n * p.out_batch_stride * 16 : nullptr;
+  const float inv_l = 1.f / lsum;
+#pragma unroll
+  for (int c = 0; c < DC; ++c)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 h, lo4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = ot[c][g * 4 + e] * inv_l;
+        const __bf16 hb = (__bf16)v;
+        h[e] = hb;
+        lo4[e] = (__bf16)(v - (float)hb);
+      }
+      const int64_t off = ((((int64_t)slot * DC + c) * 4 + g) * p.out_plane_stride + qpix) * 16 + lh * 8;
+      *(bf16x4*)(out_hi + off) = h;
+      if (out_lo != nullptr) *(bf16x4*)(out_lo + off) = lo4;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ channel attention weights
 constexpr int CA_TOK = 2048;                 // tokens per partial Gram matrix
 constexpr int CA_REC = 32 * 32 + 64;         // floats per partial: G[32][32], |q|^2[32], |k|^2[32]
@@ -656,6 +884,9 @@ extern "C" int rsa_rect_attention(const rsa_rect_attn_params* p, void* stream) {
   if (misaligned(p->qkv_hi) || misaligned(p->qkv_lo) || misaligned(p->bias_frag) || misaligned(p->out_hi) || misaligned(p->out_lo))
     return set_error(RSA_E_ALIGN, "rect_attention: pointers must be 16-byte aligned");
   const bool cross = p->kwin_h > 0 || p->kwin_w > 0;
+  const int DCh = p->head_chunks < 1 ? 1 : p->head_chunks;
+  if (DCh > 4) return set_error(RSA_E_UNSUPPORTED, "rect_attention: head_chunks must be 1..4 (head_dim <= 128)");
+  if (DCh > 1 && cross) return set_error(RSA_E_UNSUPPORTED, "rect_attention: wide heads (head_chunks > 1) are self-attention only");
   if (cross) {
     if (p->kwin_h < 1 || p->kwin_w < 1 || p->kpad_h < 0 || p->kpad_w < 0) return set_error(RSA_E_ARG, "rect_attention: bad key window");
     if (p->shift_h != 0 || p->Hp != p->H || p->Wp != p->W) return set_error(RSA_E_UNSUPPORTED, "rect_attention: the cross-window mode takes no shift and no padding");
@@ -665,8 +896,20 @@ extern "C" int rsa_rect_attention(const rsa_rect_attn_params* p, void* stream) {
   const int T = tiles <= 1 ? 1 : tiles <= 2 ? 2 : tiles <= 4 ? 4 : 8;
   const int64_t blocks = (int64_t)p->batch * (p->Hp / p->win_h) * (p->Wp / p->win_w) * p->heads;
   if (blocks > 0x7fffffff) return set_error(RSA_E_UNSUPPORTED, "rect_attention: too many windows");
-  const dim3 grid((unsigned)blocks), block(256);
   hipStream_t s = (hipStream_t)stream;
+  if (DCh > 1) {
+    const dim3 gridw((unsigned)blocks), blockw(512);
+#define RSA_RAW(PROD, DC) hipLaunchKernelGGL((rect_attention_wide_kernel<PROD, DC>), gridw, blockw, 0, s, *p, T)
+    if (p->products == 3) {
+      if (DCh == 2) RSA_RAW(3, 2); else if (DCh == 3) RSA_RAW(3, 3); else RSA_RAW(3, 4);
+    } else {
+      if (DCh == 2) RSA_RAW(1, 2); else if (DCh == 3) RSA_RAW(1, 3); else RSA_RAW(1, 4);
+    }
+#undef RSA_RAW
+    const hipError_t rcw = hipGetLastError();
+    return rcw ? set_error(rcw, "rect_attention: launch failed") : RSA_OK;
+  }
+  const dim3 grid((unsigned)blocks), block(256);
 #define RSA_RA(PROD, TT) hipLaunchKernelGGL((rect_attention_kernel<PROD, TT>), grid, block, 0, s, *p)
   if (p->products == 3) {
     if (T == 1) RSA_RA(3, 1); else if (T == 2) RSA_RA(3, 2); else if (T == 4) RSA_RA(3, 4); else RSA_RA(3, 8);

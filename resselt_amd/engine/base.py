@@ -32,7 +32,7 @@ def conv_algorithmic_bytes(p: L.ConvParams) -> int:
     if p.out_hi:
         total += (p.cout + 7) // 8 * 16 * (2 if p.out_lo else 1) * px_out
     if p.out_nchw:
-        esize = {L.F32: 4, L.F16: 2, L.BF16: 2}[p.out_dtype]
+        esize = {L.F32: 4, L.F16: 2, L.BF16: 2, L.U8: 1}[p.out_dtype]
         total += p.cout * esize * px_out * (2 if p.out_base else 1)
     return total
 
@@ -200,20 +200,45 @@ class EngineModule(nn.Module):
                 self._drop_plan(k)
         return w
 
+    #: models whose first layout kernel and last store take 8-bit images directly set this (``model(uint8 [N, H, W, C]) -> uint8 [N, H*s, W*s, C]``)
+    supports_u8 = False
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         ops.require_cuda(x, type(self).__name__)
+        if x.dtype == torch.uint8:
+            return self._forward_u8(x)
         if x.dim() != 4:
             raise ValueError(f'expected a [N, C, H, W] tensor, got shape {tuple(x.shape)}')
         ops.rsa_dtype(x.dtype)  # raises for unsupported dtypes
+        return self._forward(x, tuple(x.shape))
+
+    def _forward_u8(self, img: torch.Tensor) -> torch.Tensor:
+        """8-bit image in, 8-bit image out ([H, W, C] or [N, H, W, C], channel-interleaved): ``/255`` happens in the first layout kernel and
+        ``clamp(0, 1) * 255`` + round-half-even in the last convolution's store when the model supports it; otherwise two extra kernels
+        do the same around an fp32 forward (bit-identical results either way)."""
+        if img.dim() not in (3, 4):
+            raise ValueError(f'expected a uint8 [N, H, W, C] or [H, W, C] image, got shape {tuple(img.shape)}')
+        squeeze = img.dim() == 3
+        if squeeze:
+            img = img.unsqueeze(0)
+        if self.supports_u8:
+            n, h, w, c = img.shape
+            y = self._forward(img.contiguous(), (n, c, h, w))
+        else:
+            y = ops.nchw_to_image_u8(self._forward(ops.image_u8_to_nchw(img, torch.float32), None))
+        return y[0] if squeeze else y
+
+    def _forward(self, x: torch.Tensor, shape) -> torch.Tensor:
+        shape = tuple(x.shape) if shape is None else shape
         first = next(self.parameters(), None)
         if first is not None and first.device != x.device:
             raise RuntimeError(f'model parameters are on {first.device} but the input is on {x.device}')
         packed = self._weights(x.device)
-        key = (tuple(x.shape), x.dtype, str(x.device), self.products)
+        key = (shape, x.dtype, str(x.device), self.products)
         entry = self._plans.pop(key, None)
         if entry is None:
             plan = Plan(x.device)
-            set_input, get_output = self._build_plan(plan, packed, tuple(x.shape), x.dtype, self.products)
+            set_input, get_output = self._build_plan(plan, packed, shape, x.dtype, self.products)
             plan.flush()
             entry = [plan, set_input, get_output, None]
         self._plans[key] = entry  # most recently used last

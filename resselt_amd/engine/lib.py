@@ -17,7 +17,7 @@ _lib: Optional[C.CDLL] = None
 # enum rsa_act
 ACT_NONE, ACT_LRELU, ACT_MISH, ACT_SILU, ACT_GELU, ACT_SPAB_GATE, ACT_PRELU = range(7)
 # enum rsa_dtype
-F32, F16, BF16 = range(3)
+F32, F16, BF16, U8 = range(4)
 
 
 class ConvParams(C.Structure):
@@ -164,6 +164,7 @@ class RectAttnParams(C.Structure):
         ('kwin_w', C.c_int32),
         ('kpad_h', C.c_int32),
         ('kpad_w', C.c_int32),
+        ('head_chunks', C.c_int32),
     ]
 
 

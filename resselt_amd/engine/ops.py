@@ -11,14 +11,14 @@ from . import lib as L
 from .pack import pack_conv_weights, pad_bias  # noqa: F401  (pad_bias re-exported for the model files)
 from .tensors import Planes
 
-_TORCH_TO_RSA = {torch.float32: L.F32, torch.float16: L.F16, torch.bfloat16: L.BF16}
+_TORCH_TO_RSA = {torch.float32: L.F32, torch.float16: L.F16, torch.bfloat16: L.BF16, torch.uint8: L.U8}
 
 
 def rsa_dtype(dt: torch.dtype) -> int:
     try:
         return _TORCH_TO_RSA[dt]
     except KeyError:
-        raise TypeError(f'resselt_amd supports float32/float16/bfloat16 tensors, got {dt}') from None
+        raise TypeError(f'resselt_amd supports float32/float16/bfloat16 tensors (and uint8 [N, H, W, C] images), got {dt}') from None
 
 
 def current_stream_ptr(device) -> int:
@@ -178,6 +178,8 @@ def conv_params(
     if out_nchw is not None:
         r = max(pixel_shuffle, 1)
         exp = (x.n, wts.cout // (r * r), H * r, W * r)
+        if out_nchw.dtype == torch.uint8:  # 8-bit image, channel-interleaved
+            exp = (x.n, H * r, W * r, wts.cout // (r * r))
         if tuple(out_nchw.shape) != exp or not out_nchw.is_contiguous():
             raise ValueError(f'out_nchw must be contiguous {exp}, got {tuple(out_nchw.shape)}')
         p.out_nchw = out_nchw.data_ptr()
@@ -213,7 +215,10 @@ def nchw_to_planes(x: torch.Tensor, out: Planes, mean: torch.Tensor | None = Non
     require_cuda(x, 'nchw_to_planes')
     if not x.is_contiguous():
         x = x.contiguous()
-    n, c, h, w = x.shape
+    if x.dtype == torch.uint8:  # 8-bit image [N, H, W, C]: v = byte / 255 happens in the same kernel
+        n, h, w, c = x.shape
+    else:
+        n, c, h, w = x.shape
     r = unshuffle
     if out.n != n or out.h * r < h or out.w * r < w or out.planes < (c * r * r + 7) // 8:
         raise ValueError('output planes do not match the input tensor')

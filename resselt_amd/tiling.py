@@ -114,6 +114,8 @@ def upscale(model, image: torch.Tensor, tile: tuple[int, int] | None = None, hal
     """
     from .engine import ops
 
+    if getattr(model, 'supports_u8', False) and image.dtype == torch.uint8:
+        return _upscale_u8(model, image, tile, halo, align, scale)
     squeeze = image.dim() == 3
     x = ops.image_u8_to_nchw(image, dtype)
     if scale is None:
@@ -126,6 +128,28 @@ def upscale(model, image: torch.Tensor, tile: tuple[int, int] | None = None, hal
     else:
         y = upscale_tiled(model, x, scale, tile, halo, align)
     out = ops.nchw_to_image_u8(y)
+    return out[0] if squeeze else out
+
+
+def _upscale_u8(model, image: torch.Tensor, tile, halo: int, align: int, scale) -> torch.Tensor:
+    """``upscale`` for models that read and write 8-bit images themselves (no separate conversion passes): whole image, or tiles."""
+    squeeze = image.dim() == 3
+    img = image.unsqueeze(0) if squeeze else image
+    if scale is None:
+        scale = model.parameters_info.upscale
+    n, h, w, c = img.shape
+    if tile is None or (h <= tile[0] and w <= tile[1]):
+        out = model(img)
+    else:
+        rows, cols = -(-h // tile[0]), -(-w // tile[1])
+        out = None
+        for t in plan_tiles(h, w, rows, cols, halo, align):
+            y = model(img[:, t.ry0 : t.ry1, t.rx0 : t.rx1].contiguous())
+            if out is None:
+                out = torch.empty((n, h * scale, w * scale, y.shape[3]), dtype=torch.uint8, device=y.device)
+            oy, ox = (t.y0 - t.ry0) * scale, (t.x0 - t.rx0) * scale
+            th, tw = t.shape
+            out[:, t.y0 * scale : t.y1 * scale, t.x0 * scale : t.x1 * scale] = y[:, oy : oy + th * scale, ox : ox + tw * scale]
     return out[0] if squeeze else out
 
 

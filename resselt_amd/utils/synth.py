@@ -542,3 +542,77 @@ def rtmosr_state_dict(scale=2, dim=32, ffn_expansion=2.0, n_blocks=2, unshuffle_
             _conv(sd, f'{b}.fc2', dim, hidden, 1, seed)
     _repconv(sd, 'to_img.0', 3 * s_int * s_int, dim, seed)
     return sd
+
+
+def drct_block_dims(embed_dim: int, gc: int, num_heads: int):
+    """(dim, heads, mlp_ratio scale, shifted) of the five Swin blocks of a DRCT dense group (reference archs/drct/arch.py:225-298)."""
+    out = []
+    for j in range(5):
+        dim = embed_dim + j * gc
+        heads = num_heads if j == 0 else num_heads - (dim % num_heads)
+        out.append((dim, heads, j in (1, 3)))
+    return out
+
+
+def drct_state_dict(in_chans=3, embed_dim=180, num_layers=2, num_heads=6, window=16, mlp_ratio=2.0, gc=32, upscale=2, resi='1conv', img_size=64,
+                    seed=0):  # fmt: skip
+    """Keys of the reference DRCT module (archs/drct/arch.py:617-792) incl. its registered buffers (relative_position_index, attn_mask of
+    the shifted blocks swin2 / swin4).  The loader fixes depths = (6,) * num_layers and reads one head count per layer."""
+    sd: OrderedDict = OrderedDict()
+    C = embed_dim
+
+    def lin(name, cout, cin):
+        sd[f'{name}.weight'] = synth_tensor(f'{name}.weight', (cout, cin), cin, seed)
+        sd[f'{name}.bias'] = synth_tensor(f'{name}.bias', (cout,), cin, seed)
+
+    def ln(name, c):
+        sd[f'{name}.weight'] = 1.0 + synth_tensor(f'{name}.weight', (c,), 16, seed)
+        sd[f'{name}.bias'] = synth_tensor(f'{name}.bias', (c,), 16, seed)
+
+    coords = torch.stack(torch.meshgrid([torch.arange(window), torch.arange(window)], indexing='ij')).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += window - 1
+    rel[:, :, 1] += window - 1
+    rel[:, :, 0] *= 2 * window - 1
+    rp_index = rel.sum(-1)
+
+    def shift_mask():
+        s_ = window // 2
+        img = torch.zeros(1, img_size, img_size, 1)
+        cnt = 0
+        for hs in (slice(0, -window), slice(-window, -s_), slice(-s_, None)):
+            for ws in (slice(0, -window), slice(-window, -s_), slice(-s_, None)):
+                img[:, hs, ws, :] = cnt
+                cnt += 1
+        mw = img.view(1, img_size // window, window, img_size // window, window, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, window * window)
+        d = mw.unsqueeze(1) - mw.unsqueeze(2)
+        return torch.where(d != 0, torch.full_like(d, -100.0), torch.zeros_like(d))
+
+    _conv(sd, 'conv_first', C, in_chans, 3, seed)
+    ln('patch_embed.norm', C)
+    for i in range(num_layers):
+        for j, (dim, heads, shifted) in enumerate(drct_block_dims(C, gc, num_heads), start=1):
+            b = f'layers.{i}.swin{j}'
+            hidden = int(dim * (mlp_ratio if j <= 3 else 1))
+            if shifted:
+                sd[f'{b}.attn_mask'] = shift_mask()
+            ln(f'{b}.norm1', dim)
+            sd[f'{b}.attn.relative_position_bias_table'] = synth_tensor(f'{b}.attn.relative_position_bias_table', ((2 * window - 1) ** 2, heads), 16, seed)
+            sd[f'{b}.attn.relative_position_index'] = rp_index.clone()
+            lin(f'{b}.attn.qkv', 3 * dim, dim)
+            lin(f'{b}.attn.proj', dim, dim)
+            ln(f'{b}.norm2', dim)
+            lin(f'{b}.mlp.fc1', hidden, dim)
+            lin(f'{b}.mlp.fc2', dim, hidden)
+            _conv(sd, f'layers.{i}.adjust{j}', gc if j < 5 else C, dim, 1, seed)
+    ln('norm', C)
+    if resi == '1conv':
+        _conv(sd, 'conv_after_body', C, C, 3, seed)
+    _conv(sd, 'conv_before_upsample.0', 64, C, 3, seed)
+    if upscale == 3:
+        _conv(sd, 'upsample.0', 9 * 64, 64, 3, seed)
+    else:
+        for u in range(int(np.log2(upscale))):
+            _conv(sd, f'upsample.{2 * u}', 4 * 64, 64, 3, seed)
+    _conv(sd, 'conv_last', in_chans, 64, 3, seed)
+    return sd

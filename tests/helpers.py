@@ -29,7 +29,7 @@ def synth_state_dict(meta):
         if k in kw:
             kw[k] = tuple(kw[k])
     fn = {'esrgan': synth.rrdbnet_state_dict, 'spanplus': synth.spanplus_state_dict, 'span': synth.span_state_dict,
-          'swinir': getattr(synth, 'swinir_state_dict', None), 'compact': synth.compact_state_dict, 'dat': getattr(synth, 'dat_state_dict', None), 'spanpp': getattr(synth, 'spanpp_state_dict', None), 'hat': getattr(synth, 'hat_state_dict', None), 'rtmosr': getattr(synth, 'rtmosr_state_dict', None)}[meta['arch']]  # fmt: skip
+          'swinir': getattr(synth, 'swinir_state_dict', None), 'compact': synth.compact_state_dict, 'dat': getattr(synth, 'dat_state_dict', None), 'spanpp': getattr(synth, 'spanpp_state_dict', None), 'hat': getattr(synth, 'hat_state_dict', None), 'rtmosr': getattr(synth, 'rtmosr_state_dict', None), 'drct': getattr(synth, 'drct_state_dict', None)}[meta['arch']]  # fmt: skip
     return fn(seed=meta['seed'], **kw)
 
 
@@ -66,6 +66,10 @@ def oracle_forward(meta, sd, x):
         from oracle.hat import hat_forward
 
         return hat_forward(sd, x)
+    if meta['arch'] == 'drct':
+        from oracle.drct import drct_forward
+
+        return drct_forward(sd, x)
     if meta['arch'] == 'dat':
         from oracle.dat import dat_forward
 

@@ -9,7 +9,7 @@ import torch
 
 from helpers import golden_names, load_golden, oracle_forward, synth_state_dict
 
-E2E = golden_names('rrdbnet_') + golden_names('spanplus_') + golden_names('span_') + golden_names('swinir_') + golden_names('compact_') + golden_names('dat_') + golden_names('spanpp_') + golden_names('hat_') + golden_names('rtmosr_')
+E2E = golden_names('rrdbnet_') + golden_names('spanplus_') + golden_names('span_') + golden_names('swinir_') + golden_names('compact_') + golden_names('dat_') + golden_names('spanpp_') + golden_names('hat_') + golden_names('rtmosr_') + golden_names('drct_')
 
 
 @pytest.mark.parametrize('name', E2E)

@@ -141,6 +141,20 @@ def test_uint8_image_round_trip_and_upscale_helper(device):
     assert torch.equal(one, manual)
     tiled = upscale(m, img[0].to(device), tile=(24, 32), halo=16, dtype=torch.float32)
     assert (tiled.int() - one.int()).abs().max().item() <= 1  # nb=2: receptive field < halo, so at most a rounding tie
+    # the fused path itself: model(uint8 [N, H, W, C]) reads the bytes in the layout kernel and writes bytes from the last convolution's
+    # store (rsa_dtype RSA_U8); bit-identical to the two conversion kernels around an fp32 forward, also with a row-banded tail
+    both = m(img.to(device))
+    manual2 = ops.nchw_to_image_u8(m(ops.image_u8_to_nchw(img.to(device))))
+    assert both.dtype == torch.uint8 and tuple(both.shape) == (2, 148, 212, 3) and torch.equal(both, manual2)
+    m.tail_band_rows = 16
+    assert torch.equal(m(img.to(device)), manual2) and torch.equal(m(ops.image_u8_to_nchw(img.to(device))), m.__class__.forward(m, ops.image_u8_to_nchw(img.to(device))))
+    banded = m(ops.image_u8_to_nchw(img.to(device)))
+    m.tail_band_rows = 4096
+    assert torch.equal(banded, m(ops.image_u8_to_nchw(img.to(device))))  # bands change nothing, bit for bit
+    # a model whose kernels do not take 8-bit images (base image in the final store) goes through the conversion kernels
+    c = resselt_amd.load_from_state_dict(dict(synth.compact_state_dict(num_feat=32, num_conv=3, upscale=2, seed=4))).to(device)
+    cu = c(img[0].to(device))
+    assert cu.dtype == torch.uint8 and torch.equal(cu, ops.nchw_to_image_u8(c(ops.image_u8_to_nchw(img[:1].to(device))))[0])
 
 
 def test_graph_replay_matches_eager(device):

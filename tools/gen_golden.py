@@ -231,6 +231,21 @@ def hat_cases():
         save(name, dict(arch='hat', synth=kw, seed=seed, metadata=meta_of(model), mode='eval'), x=x, y=y)
 
 
+def drct_cases():
+    """DRCT end to end (dense groups of five Swin blocks with 30..122-channel heads; no stochastic layers, train mode == eval mode)."""
+    cases = [
+        ('drct_x2_e180_g32_l1_40x50', dict(num_layers=1, upscale=2), (1, 3, 40, 50), 201),
+        ('drct_x4_e180_g32_l2_48x64', dict(num_layers=2, upscale=4), (1, 3, 48, 64), 202),
+        ('drct_x3_e60_g16_w8_l2_33x33', dict(embed_dim=60, gc=16, window=8, num_layers=2, upscale=3, mlp_ratio=4.0), (1, 3, 33, 33), 203),
+    ]
+    for name, kw, shape, seed in cases:
+        sd = synth.drct_state_dict(seed=seed, **kw)
+        model = resselt.load_from_state_dict(dict(sd))
+        x = synth.synth_input(shape, seed)
+        y = model(x)
+        save(name, dict(arch='drct', synth=kw, seed=seed, metadata=meta_of(model)), x=x, y=y)
+
+
 def rtmosr_cases():
     """RTMoSR end to end, eval mode (every RepConv / OmniShift re-parameterised; the train-mode branches are the same function)."""
     cases = [
@@ -270,7 +285,7 @@ def registry_cases():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['esrgan', 'blocks', 'span', 'compact', 'registry', 'swinir', 'dat', 'spanpp', 'hat', 'rtmosr']
+    which = sys.argv[1:] or ['esrgan', 'blocks', 'span', 'compact', 'registry', 'swinir', 'dat', 'spanpp', 'hat', 'rtmosr', 'drct']
     if 'esrgan' in which:
         esrgan_cases()
     if 'blocks' in which:
@@ -285,6 +300,8 @@ if __name__ == '__main__':
         spanpp_cases()
     if 'hat' in which:
         hat_cases()
+    if 'drct' in which:
+        drct_cases()
     if 'rtmosr' in which:
         rtmosr_cases()
     if 'registry' in which:
