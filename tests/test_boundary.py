@@ -128,7 +128,7 @@ def test_esrgan_roundtrip_and_new_arch_fix():
 
 def test_detection_claims_match_reference():
     meta, _ = load_golden('registry_claims')
-    ours = {'rrdbnet_old': 'ESRGAN', 'spanplus_ps': 'spanplus', 'spanplus_dys': 'spanplus', 'span': 'SPAN', 'compact': 'Compact', 'swinir': 'SwinIR', 'dat': 'dat', 'spanpp': 'SpanPP', 'hat': 'HAT', 'rtmosr': 'RTMoSR'}
+    ours = {'rrdbnet_old': 'ESRGAN', 'spanplus_ps': 'spanplus', 'spanplus_dys': 'spanplus', 'span': 'SPAN', 'compact': 'Compact', 'swinir': 'SwinIR', 'dat': 'dat', 'spanpp': 'SpanPP', 'hat': 'HAT', 'rtmosr': 'RTMoSR', 'drct': 'DRCT'}
     for tag, uid in ours.items():
         assert meta['claims'][tag] == uid
     built = {
@@ -142,6 +142,7 @@ def test_detection_claims_match_reference():
         'spanpp': synth.spanpp_state_dict(feature_channels=16, implicit_dim=32, latent_layers=1),
         'hat': synth.hat_state_dict(),
         'rtmosr': synth.rtmosr_state_dict(),
+        'drct': synth.drct_state_dict(num_layers=1),
     }
     for tag, sd in built.items():
         hit = [a.id for a in resselt_amd.archs.internal_registry if a.detect(sd)]

@@ -275,6 +275,7 @@ def registry_cases():
         ('dat', synth.dat_state_dict()),
         ('hat', synth.hat_state_dict()),
         ('rtmosr', synth.rtmosr_state_dict()),
+        ('drct', synth.drct_state_dict(num_layers=1)),
         ('spanpp', synth.spanpp_state_dict(feature_channels=16, implicit_dim=32, latent_layers=1)),
     ):
         for arch in resselt.archs.internal_registry.store.values():
