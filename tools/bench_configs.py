@@ -55,6 +55,9 @@ def main():
         'hat_x4_bf16_512': (
             synth.hat_state_dict(embed_dim=180, depths=(6,) * 6, num_heads=(6,) * 6, window=16, upscale=4, mlp_ratio=2.0),
             (1, 3, 512, 512), torch.bfloat16, None, None),
+        # DRCT x4 at its published size (embed 180, 6 dense groups, 6 heads, window 16, gc 32, mlp 2)
+        'drct_x4_bf16_512': (synth.drct_state_dict(num_layers=6, upscale=4), (1, 3, 512, 512), torch.bfloat16, None, None),
+        'compact_x4_fp16_b8_512': (synth.compact_state_dict(num_feat=64, num_conv=16, upscale=4), (8, 3, 512, 512), torch.float16, None, None),
     }  # fmt: skip
     for name, (sd, shape, dt, flop_px, bytes_px) in cases.items():
         if args.only and args.only not in name:
@@ -65,7 +68,7 @@ def main():
             x = synth.synth_input(shape, seed=0).to(dev).to(dt)
             y, t = timed(model, x, args.reps)
             out_px = y.shape[0] * y.shape[2] * y.shape[3]
-            macs = model.macs_per_input_pixel() * shape[0] * shape[2] * shape[3]
+            macs = (model.macs_per_input_pixel() if hasattr(model, 'macs_per_input_pixel') else 0) * shape[0] * shape[2] * shape[3]
             rec = dict(config=name, precision=prec, in_shape=list(shape), io_dtype=str(dt).split('.')[-1], ms=round(t * 1e3, 3),
                        out_mp_s=round(out_px / 1e6 / t, 2), algorithmic_tflops=round(2 * macs / t / 1e12, 2),
                        launches=model.launches_per_forward(), finite=bool(torch.isfinite(y.float()).all()))  # fmt: skip
