@@ -9,6 +9,7 @@ descriptors that ``rsa_conv2d_list`` executes with one host call.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Callable
 
 import torch
@@ -128,15 +129,33 @@ class EngineModule(nn.Module):
         # of the input into, and of the output out of, graph-owned buffers.  Off by default.
         self.use_graph: bool = False
         self._packed: dict = {}
+        self._packed_versions = None
+        self._lock = threading.RLock()  # a plan's buffers are module state: one forward at a time per module (the reference nn.Module is re-entrant)
         self._plans: dict = {}
         self._max_plans = 8
         self.max_plan_bytes = 40 << 30  # byte budget of the cached plans' buffers (least recently used plans are dropped first)
+
+    # -- copy / pickle: caches and the lock are per-instance runtime state, never part of the module's value --
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state['_packed'], state['_plans'], state['_packed_versions'] = {}, {}, None
+        state.pop('_lock', None)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._lock = threading.RLock()
 
     # -- cache invalidation: anything that can change parameter values, dtype or device --
     def _drop_plan(self, key) -> None:
         entry = self._plans.pop(key)
         entry[0].release()
         entry[1:] = [None, None, None]  # input setter / output getter / graph: closures over the plan's buffers
+
+    def invalidate(self) -> None:
+        """Drop the packed weights and every plan.  Called automatically by load_state_dict / .to() / .half() and when a parameter's
+        version counter changes; call it yourself after editing parameters through ``.data`` (PyTorch does not version those edits)."""
+        self._invalidate()
 
     def _invalidate(self) -> None:
         self._packed = {}
@@ -191,6 +210,11 @@ class EngineModule(nn.Module):
 
     def _weights(self, device):
         key = (str(device), self.products)
+        # in-place edits of a parameter (p.data.copy_, optimizer steps, load into .data) bump its version counter: repack when any changed
+        versions = tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+        if versions != self._packed_versions:
+            self._packed = {}
+            self._packed_versions = versions
         w = self._packed.get(key)
         if w is None:
             with torch.no_grad():
@@ -229,6 +253,10 @@ class EngineModule(nn.Module):
         return y[0] if squeeze else y
 
     def _forward(self, x: torch.Tensor, shape) -> torch.Tensor:
+        with self._lock:
+            return self._forward_locked(x, shape)
+
+    def _forward_locked(self, x: torch.Tensor, shape) -> torch.Tensor:
         shape = tuple(x.shape) if shape is None else shape
         first = next(self.parameters(), None)
         if first is not None and first.device != x.device:

@@ -338,6 +338,23 @@ def lib_path() -> str:
     return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), _LIB_NAME)
 
 
+def _warn_if_stale(path: str) -> None:
+    """The build stamps the library with the hash of the sources it was built from (build.py); a library that no longer matches the
+    sources next to it still loads (the GPU box only has the prebuilt file), but says so."""
+    try:
+        from .. import build as B
+
+        if os.path.abspath(path) != os.path.abspath(B.OUT) or not os.path.isdir(B.CSRC):
+            return
+        have = open(B.STAMP).read().strip() if os.path.exists(B.STAMP) else None
+        if have != B._hash():
+            import warnings
+
+            warnings.warn(f'{_LIB_NAME} was built from other sources than the ones in {B.CSRC} (stamp {str(have)[:12]}); run `python -m resselt_amd.build`', RuntimeWarning, stacklevel=3)
+    except OSError:
+        pass
+
+
 def load() -> C.CDLL:
     """Load the HIP library once; fail loudly when it has not been built."""
     global _lib
@@ -349,6 +366,7 @@ def load() -> C.CDLL:
             f'{_LIB_NAME} not found at {path}: build it with `python -c "import __graft_entry__ as g; g.build()"` '
             '(hipcc --offload-arch=gfx950). resselt_amd has no CPU fallback.'
         )
+    _warn_if_stale(path)
     lib = C.CDLL(path)
     for name in EXPORTS:
         if not hasattr(lib, name):

@@ -185,3 +185,21 @@ def test_torchscript_pt(tmp_path):
     torch.jit.script(Tiny()).save(str(tmp_path / 'ts.pt'))
     with pytest.raises(ArchitectureNotFound):  # loads as TorchScript, but no architecture claims its keys
         resselt_amd.load_from_file(str(tmp_path / 'ts.pt'))
+
+
+def test_engine_module_copies_and_tracks_in_place_parameter_edits():
+    """nn.Module conveniences of the returned object: deepcopy / pickle work (the plan cache and the forward lock are
+    runtime state, not part of the module's value), and an in-place parameter edit invalidates the packed weights."""
+    import copy
+
+    m = resselt_amd.load_from_state_dict(dict(synth.rrdbnet_state_dict(nb=1, nf=16, seed=2)))
+    m2 = copy.deepcopy(m)
+    assert m2 is not m and m2.parameters_info == m.parameters_info
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    m3 = pickle.loads(pickle.dumps(m))
+    assert list(m3.state_dict()) == list(m.state_dict())
+    v0 = tuple(p._version for p in m.parameters())
+    with torch.no_grad():
+        next(m.parameters()).mul_(2.0)
+    assert tuple(p._version for p in m.parameters()) != v0  # what EngineModule._weights keys the packed blobs on
+    m.invalidate()  # the explicit form, for edits through `.data` (which PyTorch does not version)
