@@ -28,7 +28,7 @@ def _hash() -> str:
     files = sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h'))
     files.append(os.path.join(ROOT, 'include', 'resselt_amd.h'))
     for f in files:
-        h.update(f.encode())
+        h.update(os.path.relpath(f, ROOT).encode())  # relative: the same tree hashes the same wherever it is checked out
         with open(f, 'rb') as fh:
             h.update(fh.read())
     return h.hexdigest()

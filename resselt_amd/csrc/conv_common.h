@@ -282,6 +282,20 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
             split2(v[e][2], v[e][3], h[e][1], l[e][1]);
           }
           const int odd = lg & 1;  // odd lanes keep pixel-tile 2k+1 and give away their half of 2k; even lanes the reverse
+          // v_permlane16_swap_b32 a, b swaps the odd 16-lane rows of a with the even rows of b: with a = this lane's half of pixel-tile
+          // 2k and b = its half of 2k+1, an even lane ends up with (own half of 2k, partner's half of 2k) and an odd lane with
+          // (partner's half of 2k+1, own half of 2k+1) -- the full 16-byte units, one instruction per register pair, no selects
+#ifndef RSA_EPI_SHFL
+          typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+          const u32x2 h0 = __builtin_amdgcn_permlane16_swap(h[0][0], h[1][0], false, false);
+          const u32x2 h1 = __builtin_amdgcn_permlane16_swap(h[0][1], h[1][1], false, false);
+          const u32x2 l0 = __builtin_amdgcn_permlane16_swap(l[0][0], l[1][0], false, false);
+          const u32x2 l1 = __builtin_amdgcn_permlane16_swap(l[0][1], l[1][1], false, false);
+          const int pt = pp * 2 + odd;
+          // unit = channels 8*(plane) .. +7: the even lane owns channels 0-3, the odd lane channels 4-7
+          const uint4 uh = make_uint4(h0.x, h1.x, h0.y, h1.y);
+          const uint4 ul = make_uint4(l0.x, l1.x, l0.y, l1.y);
+#else  // round-1 form (ds_bpermute + selects), kept for A/B builds
           uint32_t sh[2], sl[2], rh[2], rl[2];
 #pragma unroll
           for (int d = 0; d < 2; ++d) {
@@ -291,9 +305,9 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
             rl[d] = (uint32_t)__shfl_xor((int)sl[d], 16);
           }
           const int pt = pp * 2 + odd;
-          // unit = channels 8*(plane) .. +7: the even lane owns channels 0-3, the odd lane channels 4-7
           const uint4 uh = odd ? make_uint4(rh[0], rh[1], h[1][0], h[1][1]) : make_uint4(h[0][0], h[0][1], rh[0], rh[1]);
           const uint4 ul = odd ? make_uint4(rl[0], rl[1], l[1][0], l[1][1]) : make_uint4(l[0][0], l[0][1], rl[0], rl[1]);
+#endif
           // the partner lane has the same pixel column li and the same plane; both halves are valid together (same cvalid)
           if (pvalid_of(pt) && cvalid) {
             const uint32_t uoff = (pllane + lpix_of(pt)) * 16u;
