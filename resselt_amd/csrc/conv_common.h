@@ -108,10 +108,23 @@ struct GeoLW {
 //   c0 = 16*(slab*NCT + CTW*wct + c) + 4*lg .. +3  of pixel (y0 + RPW*wpx + (pt>>1), x0 + 16*(pt&1) + li),  RPW = NPT/2.
 // OUTK = 0: split planes and/or f32 residual map (with activation / residual epilogues)
 // OUTK = 1: final plain NCHW tensor (optional activation, depth-to-space and affine), any dtype
-template <int NCT, int CTW, int NPT, int OUTK, int AC>
+// EM = epilogue SHAPE.  The generic body (EM 0) tests a dozen descriptor fields per fragment and keeps all of them live in scalar
+// registers (the descriptor is ~80 SGPRs: 130 of the 770 instructions of one generic iteration were SGPR spill reloads).  The two
+// shapes that make up an RRDBNet frame are compiled again with those tests folded:
+//   EM 1: split-plane output only (hi and lo), no residual, no f32 map, no PReLU      -- the growth convolutions (276 of 351 launches)
+//   EM 2: EM 1 + residual 1 as split planes (hi + lo) and an optional residual 2 as split planes -- conv5 of a residual dense block
+template <int NCT, int CTW, int NPT, int OUTK, int AC, int EM = 0>
 __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f32x4 (&acc)[NPT][CTW], int n, int y0, int x0, int slab, int wct,
                                               int wpx, int li, int lg) {
   constexpr int RPW = NPT / 2;
+  constexpr bool G = EM == 0;
+  const bool R1F = G && p.res1 != nullptr, R2F = G && p.res2 != nullptr;                          // residuals as f32 maps
+  const bool R1P = G ? p.res1_hi != nullptr : EM == 2, R2P = G ? p.res2_hi != nullptr : (EM == 2 && p.res2_hi != nullptr);  // as planes
+  const bool R1L = G ? p.res1_lo != nullptr : true, R2L = G ? p.res2_lo != nullptr : true;       // ... with lo planes
+  const bool OF32 = G && p.out_f32 != nullptr;
+  const bool OHI = G ? p.out_hi != nullptr : true, OLO = G ? p.out_lo != nullptr : true;
+  const bool PRELU = G && p.act == RSA_ACT_PRELU;
+  const float lin_slope = p.act == RSA_ACT_NONE ? 1.f : p.act_param;  // EM 1 / 2: act(v) = max(v, v * slope)
 #ifdef RSA_ABL_NOEPI
   if (p.H > 0) {  // timing-only build: no epilogue, but every accumulator stays live (no dead-code elimination of the MFMAs)
 #pragma unroll
@@ -151,15 +164,15 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
     biasv[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
     slopev[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (p.bias != nullptr && live) biasv[ct] = ((const f32x4*)p.bias)[c0 >> 2];  // bias is padded to a multiple of 16
-    if (p.act == RSA_ACT_PRELU && live) slopev[ct] = ((const f32x4*)p.act_vec)[c0 >> 2];  // per-channel PReLU slopes, same padding
+    if (PRELU && live) slopev[ct] = ((const f32x4*)p.act_vec)[c0 >> 2];  // per-channel PReLU slopes, same padding
   }
 
   // Residual fragments are fetched ONE STEP AHEAD (a step = one pixel-tile pair of one cout tile): the loads of step s+1 are issued
   // before the stores of step s, so they never queue behind a store of this epilogue (vmcnt retires in order and counts stores).
   // A residual is either an f32 map (res1 / res2) or split planes (res1_hi / res1_lo ...: value = hi + lo).  Plane residuals arrive
   // as two 8-byte halves of a unit (this lane's 4 channels) and are widened to f32 here, so the arithmetic below sees one form.
-  const bool has_r1 = p.res1 != nullptr || p.res1_hi != nullptr;
-  const bool has_r2 = p.res2 != nullptr || p.res2_hi != nullptr;
+  const bool has_r1 = R1F || R1P;
+  const bool has_r2 = R2F || R2P;
   auto widen = [](uint2 h, uint2 l) -> f32x4 {
     return (f32x4){__builtin_bit_cast(float, h.x << 16) + __builtin_bit_cast(float, l.x << 16),
                    __builtin_bit_cast(float, h.x & 0xffff0000u) + __builtin_bit_cast(float, l.x & 0xffff0000u),
@@ -184,21 +197,21 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
       const uint32_t poff = (rlane + lpix_of(pt)) * 16u + (uint32_t)(lg & 1) * 8u;
       nr1[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
       nr2[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (p.res1 != nullptr && okl) nr1[e] = *(const f32x4*)(r1b + foff);
-      if (p.res2 != nullptr && okl) nr2[e] = *(const f32x4*)(r2b + foff);
-      if (p.res1_hi != nullptr && okl) {
+      if (R1F && okl) nr1[e] = *(const f32x4*)(r1b + foff);
+      if (R2F && okl) nr2[e] = *(const f32x4*)(r2b + foff);
+      if (R1P && okl) {
         const uint2 h = *(const uint2*)((const char*)p.res1_hi + runit0 * 16 + poff);
-        const uint2 l = p.res1_lo != nullptr ? *(const uint2*)((const char*)p.res1_lo + runit0 * 16 + poff) : make_uint2(0u, 0u);
+        const uint2 l = R1L ? *(const uint2*)((const char*)p.res1_lo + runit0 * 16 + poff) : make_uint2(0u, 0u);
         nr1[e] = widen(h, l);
       }
-      if (p.res2_hi != nullptr && okl) {
+      if (R2P && okl) {
         const uint2 h = *(const uint2*)((const char*)p.res2_hi + runit0 * 16 + poff);
-        const uint2 l = p.res2_lo != nullptr ? *(const uint2*)((const char*)p.res2_lo + runit0 * 16 + poff) : make_uint2(0u, 0u);
+        const uint2 l = R2L ? *(const uint2*)((const char*)p.res2_lo + runit0 * 16 + poff) : make_uint2(0u, 0u);
         nr2[e] = widen(h, l);
       }
     }
   };
-  if (OUTK == 0) fetch_res(0, 0);
+  if (OUTK == 0 && EM != 1) fetch_res(0, 0);
 
 #pragma unroll
   for (int ct = 0; ct < CTW; ++ct) {
@@ -233,7 +246,8 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
           cr1[e] = nr1[e];
           cr2[e] = nr2[e];
         }
-        if (pp + 1 < RPW)
+        if (EM == 1) {
+        } else if (pp + 1 < RPW)
           fetch_res(ct, pp + 1);
         else if (ct + 1 < CTW)
           fetch_res(ct + 1, 0);
@@ -255,7 +269,12 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
             }
           } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[e][r] = act_apply<AC>(v[e][r], p.act, p.act == RSA_ACT_PRELU ? slope[r] : p.act_param);
+            for (int r = 0; r < 4; ++r) {
+              if (G)
+                v[e][r] = act_apply<AC>(v[e][r], p.act, PRELU ? slope[r] : p.act_param);
+              else
+                v[e][r] = fmaxf(v[e][r], v[e][r] * lin_slope);  // none / LeakyReLU with a slope in [0, 1]: two instructions per value
+            }
             if (has_r1 && has_f32grp && ok[e]) {
               const f32x4 rr = cr1[e];
 #pragma unroll
@@ -267,14 +286,16 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[e][r] = v[e][r] * p.beta + rr[r];
           }
+          if (G) {  // (the specialised shapes have whole cout tiles)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (c0 + r >= p.cout) v[e][r] = 0.f;
-          if (p.out_f32 != nullptr && has_f32grp && ok[e]) *(f32x4*)(f32b + foff) = (f32x4){v[e][0], v[e][1], v[e][2], v[e][3]};
+            for (int r = 0; r < 4; ++r)
+              if (c0 + r >= p.cout) v[e][r] = 0.f;
+          }
+          if (OF32 && has_f32grp && ok[e]) *(f32x4*)(f32b + foff) = (f32x4){v[e][0], v[e][1], v[e][2], v[e][3]};
         }
       }
       if (OUTK == 0) {
-        if (p.out_hi != nullptr) {  // wave-uniform: every lane takes part in the exchange
+        if (OHI) {  // wave-uniform: every lane takes part in the exchange
           uint32_t h[2][2], l[2][2];
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
@@ -312,7 +333,7 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
           if (pvalid_of(pt) && cvalid) {
             const uint32_t uoff = (pllane + lpix_of(pt)) * 16u;
             *(uint4*)(ohb + uoff) = uh;
-            if (p.out_lo != nullptr) *(uint4*)(olb + uoff) = ul;
+            if (OLO) *(uint4*)(olb + uoff) = ul;
           }
         }
       } else {
@@ -386,6 +407,15 @@ __device__ __forceinline__ void epilogue(const rsa_conv_params& p, const f32x4 (
       if (OUTK == 0) return epilogue_impl<NCT, CTW, NPT, OUTK, AC_GATE>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
       return;
     default:
+#ifndef RSA_NO_EM
+      if (OUTK == 0 && p.out_hi != nullptr && p.out_lo != nullptr && p.out_f32 == nullptr && p.res1 == nullptr && p.res2 == nullptr && p.act != RSA_ACT_PRELU &&
+          (p.cout & 15) == 0 && (p.act == RSA_ACT_NONE || (p.act_param >= 0.f && p.act_param <= 1.f))) {
+        // the two shapes of an RRDBNet frame, with the descriptor tests folded (see EM above); wave-uniform choice
+        if (p.res1_hi == nullptr && p.res2_hi == nullptr) return epilogue_impl<NCT, CTW, NPT, OUTK, AC_LINEAR, 1>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
+        if (p.res1_hi != nullptr && p.res1_lo != nullptr && (p.res2_hi == nullptr || p.res2_lo != nullptr))
+          return epilogue_impl<NCT, CTW, NPT, OUTK, AC_LINEAR, 2>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
+      }
+#endif
       return epilogue_impl<NCT, CTW, NPT, OUTK, AC_LINEAR>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
   }
 }
