@@ -27,6 +27,7 @@ def _hash() -> str:
     h = hashlib.sha256()
     files = sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h'))
     files.append(os.path.join(ROOT, 'include', 'resselt_amd.h'))
+    files.append(os.path.abspath(__file__))  # compile flags live here
     for f in files:
         h.update(os.path.relpath(f, ROOT).encode())  # relative: the same tree hashes the same wherever it is checked out
         with open(f, 'rb') as fh:
@@ -37,6 +38,10 @@ def _hash() -> str:
 def _compile(args) -> str:
     hipcc, src, obj, verbose = args
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, src, '-o', obj]
+    if os.path.basename(src).startswith('conv_inst_ring'):
+        # SLP vectorisation packs the epilogue's f32 adds / multiplies into v_pk_* instructions, which are slower beside MFMAs
+        # (MI355X guide, 'price of one filler beside MFMAs'; measured +0.4..2 % per layer: profiles/r02_i_*)
+        cmd.insert(3, '-fno-slp-vectorize')
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)
