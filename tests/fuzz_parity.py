@@ -40,6 +40,9 @@ def main():
                                                upscale=rng.choice([2, 3]), img_size=16, seed=s), 2),
         'rtmosr': lambda s: (synth.rtmosr_state_dict(scale=rng.choice([2, 4]), dim=rng.choice([32, 48]), n_blocks=2, se=rng.random() < 0.6,
                                                      dccm=rng.random() < 0.7, seed=s), 3),
+        'drct': lambda s: (synth.drct_state_dict(embed_dim=rng.choice([60, 96]), gc=16, window=rng.choice([4, 8]), num_layers=rng.choice([1, 2]), upscale=rng.choice([2, 3, 4]),
+                                                 mlp_ratio=rng.choice([2.0, 4.0]), seed=s), 9),
+        'esrganbig': lambda s: (synth.rrdbnet_state_dict(nb=2, scale=4, seed=s), 1),
         'hat': lambda s: (synth.hat_state_dict(embed_dim=60, depths=(2,), num_heads=(6,), window=rng.choice([4, 8]), upscale=rng.choice([2, 4]), seed=s), 9),
     }  # fmt: skip
     worst = 0.0
@@ -47,14 +50,18 @@ def main():
         for k in range(per_arch):
             s = rng.randrange(1 << 20)
             sd, min_hw = make(s)
-            n = rng.choice([1, 1, 2, 3])
+            n = 1 if arch == 'drct' else rng.choice([1, 1, 2, 3])
             h, w = rng.randint(min_hw, 45), rng.randint(min_hw, 45)
+            if arch == 'esrganbig':  # many tiles per workgroup, ragged edges, a row-banded tail
+                h, w = rng.randint(300, 420), rng.randint(500, 700)
             dt = rng.choice([torch.float32, torch.float32, torch.float16, torch.bfloat16])
             cin = sd['conv_first.weight'].shape[1] if arch == 'swinir_restore' else 3
             x = synth.synth_input((n, cin, h, w), seed=s).to(dt)
             with torch.no_grad():
-                ref = oracle_forward(dict(arch=arch.split('_')[0]), sd, x.float())
+                ref = oracle_forward(dict(arch='esrgan' if arch == 'esrganbig' else arch.split('_')[0]), sd, x.float())
             model = resselt_amd.load_from_state_dict(dict(sd)).to(dev)
+            if arch == 'esrganbig':
+                model.tail_band_rows = rng.choice([64, 100, 4096])
             xd = x.to(dev)
             if rng.random() < 0.3:  # a non-contiguous view of the same values
                 xd = xd.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)
