@@ -186,45 +186,75 @@ __global__ __launch_bounds__(GK_WAVES * 64, 2) void gemm_k1_kernel(const rsa_con
           const bool has_f32grp = c0 < (p4 << 2);
           const int64_t f32row = ((int64_t)n * p4 + (c0 >> 2)) * HW;
           const int64_t outrow = (int64_t)n * p.out_batch_stride + (int64_t)(p.out_plane_off + (c0 >> 3)) * p.out_plane_stride;
+          static_assert(NPT % 2 == 0, "pixel tiles are stored in pairs");
 #pragma unroll
-          for (int pt = 0; pt < NPT; ++pt) {
-            const int64_t pix = pix0 + pt * 16 + li;
-            if (pix >= HW) continue;
-            float v[4];
+          for (int pp = 0; pp < NPT / 2; ++pp) {
+            // the two pixel tiles (2pp, 2pp+1) of this cout tile: after the per-value math the lanes that hold the two halves of a
+            // 16-byte plane unit (lg, lg^1 = lanes l, l^16) swap one half each (v_permlane16_swap_b32), so that the even lane stores the
+            // whole unit of pixel tile 2pp and the odd lane the whole unit of 2pp+1: 16-byte stores instead of two 8-byte halves
+            // (the 8-byte form was store-issue bound on the write-heavy layers: qkv writes 3 GB per 1 M tokens)
+            float v[2][4];
+            int64_t pixe[2];
+            bool live[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[pt][c][r] + bias[r];
-            if (p.act == RSA_ACT_SPAB_GATE) {
-              f32x4 rr = {0.f, 0.f, 0.f, 0.f};
-              if (RES_PREFETCH) rr = pre1[c * NPT + pt];
-              else if (has_f32grp) rr = ((const f32x4*)p.res1)[f32row + pix];
+            for (int e = 0; e < 2; ++e) {
+              const int pt = pp * 2 + e;
+              const int64_t pix = pix0 + pt * 16 + li;
+              pixe[e] = pix;
+              live[e] = pix < HW;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = (v[r] + rr[r]) * (1.f / (1.f + expf(-v[r])) - 0.5f);
-            } else {
+              for (int r = 0; r < 4; ++r) v[e][r] = acc[pt][c][r] + bias[r];
+              if (p.act == RSA_ACT_SPAB_GATE) {
+                f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+                if (RES_PREFETCH) rr = pre1[c * NPT + pt];
+                else if (has_f32grp && live[e]) rr = ((const f32x4*)p.res1)[f32row + pix];
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = (p.act == RSA_ACT_GELU) ? act_apply<AC_GELU>(v[r], p.act, 0.f) : act_apply<AC_LINEAR>(v[r], p.act, p.act == RSA_ACT_PRELU ? slope[r] : p.act_param);
-              if (p.res1 != nullptr && has_f32grp) {
-                const f32x4 rr = RES_PREFETCH ? pre1[c * NPT + pt] : ((const f32x4*)p.res1)[f32row + pix];
+                for (int r = 0; r < 4; ++r) v[e][r] = (v[e][r] + rr[r]) * (1.f / (1.f + expf(-v[e][r])) - 0.5f);
+              } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + rr[r];
+                for (int r = 0; r < 4; ++r) v[e][r] = (p.act == RSA_ACT_GELU) ? act_apply<AC_GELU>(v[e][r], p.act, 0.f) : act_apply<AC_LINEAR>(v[e][r], p.act, p.act == RSA_ACT_PRELU ? slope[r] : p.act_param);
+                if (p.res1 != nullptr && has_f32grp) {
+                  f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+                  if (RES_PREFETCH) rr = pre1[c * NPT + pt];
+                  else if (live[e]) rr = ((const f32x4*)p.res1)[f32row + pix];
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) v[e][r] = v[e][r] * p.alpha + rr[r];
+                }
+              }
+              if (p.res2 != nullptr && has_f32grp) {
+                f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+                if (RES_PREFETCH) rr = pre2[c * NPT + pt];
+                else if (live[e]) rr = ((const f32x4*)p.res2)[f32row + pix];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[e][r] = v[e][r] * p.beta + rr[r];
+              }
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (c0 + r >= p.cout) v[e][r] = 0.f;
+              if (p.out_f32 != nullptr && has_f32grp && live[e]) ((f32x4*)p.out_f32)[f32row + pix] = (f32x4){v[e][0], v[e][1], v[e][2], v[e][3]};
+            }
+            if (p.out_hi != nullptr) {  // wave-uniform: every lane takes part in the exchange
+              uint32_t h[2][2], l[2][2];
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                split2(v[e][0], v[e][1], h[e][0], l[e][0]);
+                split2(v[e][2], v[e][3], h[e][1], l[e][1]);
+              }
+              typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+              const u32x2 h0 = __builtin_amdgcn_permlane16_swap(h[0][0], h[1][0], false, false);
+              const u32x2 h1 = __builtin_amdgcn_permlane16_swap(h[0][1], h[1][1], false, false);
+              const int odd = lg & 1;
+              const int64_t pixs = odd ? pixe[1] : pixe[0];  // the pixel whose whole unit this lane stores (same column li in both tiles)
+              const int64_t off = (outrow + pixs) * 16;
+              if (pixs < HW) {
+                *(uint4*)((char*)p.out_hi + off) = make_uint4(h0.x, h1.x, h0.y, h1.y);
+              }
+              if (p.out_lo != nullptr) {
+                const u32x2 l0 = __builtin_amdgcn_permlane16_swap(l[0][0], l[1][0], false, false);
+                const u32x2 l1 = __builtin_amdgcn_permlane16_swap(l[0][1], l[1][1], false, false);
+                if (pixs < HW) *(uint4*)((char*)p.out_lo + off) = make_uint4(l0.x, l1.x, l0.y, l1.y);
               }
             }
-            if (p.res2 != nullptr && has_f32grp) {
-              const f32x4 rr = RES_PREFETCH ? pre2[c * NPT + pt] : ((const f32x4*)p.res2)[f32row + pix];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = v[r] * p.beta + rr[r];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (c0 + r >= p.cout) v[r] = 0.f;
-            if (p.out_hi != nullptr) {
-              uint32_t h0, l0, h1, l1;
-              split2(v[0], v[1], h0, l0);
-              split2(v[2], v[3], h1, l1);
-              const int64_t off = (outrow + pix) * 16 + (lg & 1) * 8;
-              *(uint2*)((char*)p.out_hi + off) = make_uint2(h0, h1);
-              if (p.out_lo != nullptr) *(uint2*)((char*)p.out_lo + off) = make_uint2(l0, l1);
-            }
-            if (p.out_f32 != nullptr && has_f32grp) ((f32x4*)p.out_f32)[f32row + pix] = (f32x4){v[0], v[1], v[2], v[3]};
             __builtin_amdgcn_sched_barrier(0);
           }
         }

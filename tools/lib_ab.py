@@ -23,11 +23,12 @@ split = args.index('--')
 libs = dict(a.split('=') for a in args[:split])
 configs = [tuple(int(v) for v in a.split(',')) for a in args[split + 1 :]]
 dev = torch.device('cuda:0')
-H, W = 1080, 1920
+H, W = int(os.environ.get('AB_H', 1080)), int(os.environ.get('AB_W', 1920))
 rounds = int(os.environ.get('AB_ROUNDS', 7))
 reps = int(os.environ.get('AB_REPS', 5))
 for cin, cout in configs:
-    w = (torch.rand((cout, cin, 3, 3)) - 0.5) * 0.1
+    ks = int(os.environ.get('AB_KS', 3))
+    w = (torch.rand((cout, cin, ks, ks)) - 0.5) * 0.1
     x = tensors.Planes.empty(1, cin // 8, H, W, dev)
     x.hi.copy_(torch.randn(x.hi.shape, device=dev).to(torch.bfloat16))
     x.lo.copy_((torch.randn(x.lo.shape, device=dev) * 0.004).to(torch.bfloat16))
@@ -53,5 +54,5 @@ for cin, cout in configs:
             torch.cuda.synchronize()
             if r:
                 times[n].append(e0.elapsed_time(e1) / reps)
-    flop = 2.0 * cin * 9 * cout * H * W * 3
+    flop = 2.0 * cin * ks * ks * cout * H * W * 3
     print(f'{cin}->{cout}: ' + '  '.join(f'{n}: med {statistics.median(t):.3f} min {min(t):.3f} ({flop / statistics.median(t) / 1e9:.0f} TF)' for n, t in times.items()), flush=True)
