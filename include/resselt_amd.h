@@ -153,6 +153,7 @@ int rsa_conv_cout_tiles(int32_t cout);
  * w_packed / w_layout filled in) and pass the answer as `layout` here and as rsa_conv_params.w_layout:
  *   0  blob[chunk q][tap t][cout_tile][hi|lo][lane 0..63][8] bf16, lane l: cout = 16*tile + (l & 15), cin = 32*q + 8*(l >> 4) + j
  *   1  tap-pair order of the ring schedule (3x3, three products, whole 32-channel chunks): resselt_amd/csrc/pack.hip
+ *   2  the same per 16-channel half chunk, five K steps each (an odd number of half chunks, e.g. 48 input channels)
  * (hi = bf16 RNE of w, lo = bf16 of w - hi; only hi when products == 1).
  */
 int rsa_conv_weight_layout(const rsa_conv_params* p);

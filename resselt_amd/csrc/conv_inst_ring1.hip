@@ -1,11 +1,14 @@
-// conv_inst_ring1.hip — conv_ring<STREAMS = 1> (49..64 output channels) and the dispatch of the ring schedule.
+// conv_inst_ring1.hip — conv_ring<SHAPE = 1> (49..64 output channels) and the dispatch of the ring schedule.
 #include "conv_ring.h"
 
 namespace rsa {
 int conv_launch_ring2(const rsa_conv_params& p, hipStream_t stream);  // conv_inst_ring2.hip
+int conv_launch_ring3(const rsa_conv_params& p, hipStream_t stream);  // conv_inst_ring3.hip
 
 int conv_launch_ring(const rsa_conv_params& p, hipStream_t stream) {
-  if (((p.cout + 15) >> 4) == 2) return conv_launch_ring2(p, stream);
+  const int ct = (p.cout + 15) >> 4;
+  if (ct == 2) return conv_launch_ring2(p, stream);
+  if (ct == 3) return conv_launch_ring3(p, stream);
   return p.upsample2x ? launch_ring<1, 1, 0>(p, stream) : launch_ring<1, 0, 0>(p, stream);
 }
 
@@ -17,9 +20,9 @@ unsigned int conv_ring_aborts() {
 }  // namespace rsa
 
 #ifdef RSA_RING_DEBUG
-namespace rsa { int conv_ring2_set_dbg(unsigned v); }
+namespace rsa { int conv_ring2_set_dbg(unsigned v); int conv_ring3_set_dbg(unsigned v); }
 extern "C" int rsa_debug_ring_flags(unsigned v) {
   if (hipMemcpyToSymbol(HIP_SYMBOL(rsa::g_ring_dbg), &v, sizeof(v)) != hipSuccess) return -1;
-  return rsa::conv_ring2_set_dbg(v);
+  return rsa::conv_ring2_set_dbg(v) | rsa::conv_ring3_set_dbg(v);
 }
 #endif

@@ -1,4 +1,4 @@
-// conv_inst_ring2.hip — conv_ring<STREAMS = 2> (17..32 output channels: the growth convolutions of a residual dense block).
+// conv_inst_ring2.hip — conv_ring<SHAPE = 2> (two streams) (17..32 output channels: the growth convolutions of a residual dense block).
 #include "conv_ring.h"
 
 namespace rsa {

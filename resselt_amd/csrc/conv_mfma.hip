@@ -32,7 +32,10 @@ bool conv_ring_enabled() {
 
 // Name of the kernel a descriptor dispatches to (bench.py groups its per-kernel roofline by it; matches the rocprofv3 kernel names).
 const char* conv_kernel_name(const rsa_conv_params& p) {
-  if (p.w_layout == RSA_WL_PAIRS) return ((p.cout + 15) >> 4) == 2 ? "rsa::conv_ring<2,UP,0> (Cout<=32)" : "rsa::conv_ring<1,UP,0> (Cout 49..64)";
+  if (p.w_layout != RSA_WL_TAPS) {
+    const int ct = (p.cout + 15) >> 4;
+    return ct == 2 ? "rsa::conv_ring<2,UP,0> (Cout<=32)" : ct == 3 ? "rsa::conv_ring<3,0,0,HM> (Cout 33..48)" : "rsa::conv_ring<1,UP,0> (Cout 49..64)";
+  }
   if (p.ksize == 1 && p.cout >= 96 && p.out_nchw == nullptr) return "rsa::gemm_k1_kernel";
   if (p.ksize == 3 && p.products == 3 && conv_nct(p.cout) == 2 && p.cout <= 32) return "rsa::conv_kernel_pp";
   return p.out_nchw != nullptr ? "rsa::conv_kernel<..., OUTK=1> (final store)" : "rsa::conv_kernel";
@@ -79,10 +82,10 @@ int conv_launch(const rsa_conv_params& p, hipStream_t stream) {
     if (p.out_dtype < RSA_F32 || p.out_dtype > RSA_U8) return set_error(RSA_E_ARG, "conv: bad out_dtype");
     if (p.out_dtype == RSA_U8 && p.out_base != nullptr) return set_error(RSA_E_UNSUPPORTED, "conv: an 8-bit image store takes no base image");
   }
-  if (p.w_layout != RSA_WL_TAPS && p.w_layout != RSA_WL_PAIRS) return set_error(RSA_E_ARG, "conv: unknown w_layout");
-  if (p.w_layout == RSA_WL_PAIRS) {  // ring schedule (conv_ring.h): the descriptor carries the K order its weights were packed in
-    if (!conv_ring_eligible(p))
-      return set_error(RSA_E_ARG, "conv: w_layout 1 (tap pairs) on a descriptor the ring schedule does not take (ask rsa_conv_weight_layout)");
+  if (p.w_layout < RSA_WL_TAPS || p.w_layout > RSA_WL_HALFPAIRS) return set_error(RSA_E_ARG, "conv: unknown w_layout");
+  if (p.w_layout != RSA_WL_TAPS) {  // ring schedule (conv_ring.h): the descriptor carries the K order its weights were packed in
+    if (!conv_ring_eligible(p) || p.w_layout != conv_ring_layout(p))
+      return set_error(RSA_E_ARG, "conv: w_layout 1 / 2 (tap pairs) on a descriptor the ring schedule does not take that way (ask rsa_conv_weight_layout)");
     if (p.in_plane_stride * 32 >= (int64_t)1 << 32) return set_error(RSA_E_UNSUPPORTED, "conv: input plane too large for 32-bit lane offsets; band the image");
     const int rc = conv_launch_ring(p, stream);
     return rc ? set_error(rc, "conv: ring kernel launch failed") : RSA_OK;

@@ -1,7 +1,8 @@
-// conv_ring.h — ring schedule of the fused 3x3 convolution (split-bf16, three products) for layers with whole 32-channel input
-// chunks and 17..32 or 49..64 output channels: every convolution of a residual dense block (utilities/block.py:454-465 of the
-// reference: 64/96/128/160 -> 32 and 192 -> 64), the trunk / upsampling / HR convolutions of RRDBNet (archs/esrgan/arch.py:82-118)
-// and any other 64-channel 3x3 layer (SRVGGNetCompact's body, archs/compact/arch.py:28-52).
+// conv_ring.h — ring schedule of the fused 3x3 convolution (split-bf16, three products) for layers whose input is a whole number of
+// 16-channel half chunks and that have 17..64 output channels: every convolution of a residual dense block (utilities/block.py:454-465
+// of the reference: 64/96/128/160 -> 32 and 192 -> 64), the trunk / upsampling / HR convolutions of RRDBNet (archs/esrgan/arch.py:82-118),
+// the 48 -> 48 re-parameterised convolutions of SPAN / SPANPlus / SpanPP (archs/spanplus/arch.py:94-130; 1.5 chunks: the trailing half
+// chunk costs 5 K steps instead of 9) and any other 64-channel 3x3 layer (SRVGGNetCompact's body, archs/compact/arch.py:28-52).
 //
 // What it changes against conv_kernel.h / conv_kernel_pp.h (one workgroup barrier per 32-channel chunk, one halo fill in flight,
 // a fill has exactly one multiply phase to land):
@@ -20,9 +21,10 @@
 //   * tiles are ordered in bands of four tile rows, column-major inside a band, so that the 32 consecutive tiles an XCD works on at
 //     any time form a 4 x 8 block: the halo rows shared with the tile above / below are L2 hits instead of a second HBM fetch.
 //
-// Two shapes:  STREAMS == 2 (Cout <= 32): waves 0-3 / 4-7 are two independent streams, each with its own tiles, two ring slots
+// Three shapes:  SHAPE 2 (Cout <= 32): waves 0-3 / 4-7 are two independent streams, each with its own tiles, two ring slots
 // and loader wave (8 / 9); a wave owns 4 rows x 32 pixels x 2 cout tiles, so each activation fragment read from LDS feeds both
-// cout tiles.  STREAMS == 1 (Cout 49..64): eight waves = 2 cout groups x 4 row groups on one tile stream over all four slots.
+// cout tiles.  SHAPE 1 (Cout 49..64): eight waves = 2 cout groups x 4 row groups on one tile stream over all four slots.
+// SHAPE 3 (Cout 33..48): eight waves = 8 groups of 2 rows, each owning all 3 cout tiles, one stream.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -104,12 +106,21 @@ __device__ __forceinline__ void dma16_v(uint32_t lds_addr, gcptr vaddr) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(vaddr) : "memory");
 }
 
-template <int STREAMS, int UP, int OUTK>
-__global__ __launch_bounds__((8 + STREAMS) * 64, 3) void conv_ring(const rsa_conv_params p) {
+// SHAPE 2: two streams, 2 cout tiles (Cout 17..32).  SHAPE 1: one stream, 4 cout tiles as 2 cout groups x 4 row groups (Cout 49..64).
+// SHAPE 3: one stream, 3 cout tiles, 8 row groups of 2 rows each owning all three (Cout 33..48: the 48-channel SPAN family).
+// HM 0: the unit of work is a 32-channel chunk (two ring slots, nine K steps).  HM 1 ("half mode", layers with an odd number of half
+// chunks: 48 input channels = 3): the unit is one half chunk, five K steps -- four tap pairs and a step in which only lane groups
+// 0-1 carry tap (2,2) (the other two multiply zero weights); 15 K steps for 48 channels where whole chunks would need 18.  A second
+// kernel rather than a second loop body: two unrolled bodies in one kernel spill hundreds of registers.
+template <int SHAPE, int UP, int OUTK, int HM = 0>
+__global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(const rsa_conv_params p) {
   using R = RingGeo;
+  constexpr int STREAMS = SHAPE == 2 ? 2 : 1;
   constexpr int TH = R::TH, TW = R::TW, IH = R::IH, IW = R::IW, PS = R::PS, HALF = R::HALF, SLOT = R::SLOT, NSLOT = R::NSLOT;
-  constexpr int NCT = (STREAMS == 2) ? 2 : 4;  // cout tiles of the layer handled by one workgroup
-  constexpr int CTW = 2, NPT = 8, RPW = 4;      // per wave: 2 cout tiles x 8 pixel tiles (4 rows x 2 halves)
+  constexpr int NCT = SHAPE == 2 ? 2 : (SHAPE == 1 ? 4 : 3);  // cout tiles of the layer handled by one workgroup
+  constexpr int CTW = SHAPE == 3 ? 3 : 2;       // cout tiles per wave
+  constexpr int NPT = SHAPE == 3 ? 4 : 8;       // pixel tiles per wave (RPW rows x 2 halves)
+  constexpr int RPW = NPT / 2;
   constexpr int NCONS = (STREAMS == 2) ? 4 : 8; // consumer waves per slot
   constexpr int SPS = NSLOT / STREAMS;          // slots per stream
 
@@ -127,7 +138,8 @@ __global__ __launch_bounds__((8 + STREAMS) * 64, 3) void conv_ring(const rsa_con
   const int tiles_x = (p.W + TW - 1) / TW;
   const int tiles_y = (p.H + TH - 1) / TH;
   const int num_tiles = tiles_x * tiles_y * p.batch;
-  const int nchunks = p.cin_planes >> 2;  // whole chunks only (checked by the launcher)
+  const int nhalf = p.cin_planes >> 1;    // half chunks of 16 channels (an even number of planes: checked by the launcher)
+  const int nq = HM ? nhalf : (nhalf >> 1);  // units of work per tile: half chunks (HM 1) or whole 32-channel chunks
   const int ct_total = (p.cout + 15) >> 4;
 
   const int NWG = (int)gridDim.x;
@@ -175,7 +187,7 @@ __global__ __launch_bounds__((8 + STREAMS) * 64, 3) void conv_ring(const rsa_con
       const bool interior = y0 >= 0 && x0 >= 0 && y0 + IH <= p.H && x0 + IW <= p.W;
       // source unit of the halo origin in plane 0 of this image (used by interior tiles only, where it is inside the map)
       const int64_t tile_unit = (int64_t)n * p.in_batch_stride + (int64_t)(UP ? ty * (TH / 2) - 1 : y0) * inW + (UP ? tx * (TW / 2) - 1 : x0);
-      for (int h = 0; h < 2 * nchunks; ++h, ++k) {
+      for (int h = 0; h < nhalf; ++h, ++k) {
         const int slot = (STREAMS == 2) ? 2 * g + (k & 1) : (k & 3);
         const uint32_t use = (uint32_t)(k / SPS);  // how many times this slot has been filled before
         // the slot must have been released by all its consumers `use` times
@@ -236,14 +248,15 @@ __global__ __launch_bounds__((8 + STREAMS) * 64, 3) void conv_ring(const rsa_con
 
   // =========================== COMPUTE WAVES ===========================
   const int g = (STREAMS == 2) ? (wave >> 2) : 0;    // stream
-  const int wct = (STREAMS == 2) ? 0 : (wave >> 2);  // cout group (STREAMS == 1)
-  const int wpx = wave & 3;                          // group of 4 rows
+  const int wct = (SHAPE == 1) ? (wave >> 2) : 0;    // cout group (SHAPE 1)
+  const int wpx = (SHAPE == 3) ? wave : (wave & 3);  // group of RPW rows
   const int li = lane & 15;
   const int lg = lane >> 4;
   const int hsel = lg >> 1;  // which tap of a pair / which half in the pairing step
 
   // weights: per (chunk, K step 0..8, cout tile, hi|lo) one 1 KiB A fragment, streamed from L2 one K step ahead
-  const int nks = nchunks * 9;
+  constexpr int KSU = HM ? 5 : 9;  // K steps per unit
+  const int nks = nq * KSU;
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_packed, 0, (uint32_t)((int64_t)nks * ct_total * 2 * 64 * 16), 0x00020000);
   uint32_t woff[CTW];
 #pragma unroll
@@ -274,12 +287,7 @@ __global__ __launch_bounds__((8 + STREAMS) * 64, 3) void conv_ring(const rsa_con
   //   uA1: half A, taps (dy, 0 | 1)      + dy*IW by immediate        uA2: half A, taps (0 | 1, 2)
   //   uB1, uB2: the same for half B                                   uS : tap (2, 2) of half A (hsel 0) / half B (hsel 1)
   const int lane_u = (lg & 1) * PS + (wpx * RPW) * IW + li;
-  const int slotA0 = (STREAMS == 2) ? 2 * g * SLOT : 0;
-  int uA1 = slotA0 + lane_u + hsel;
-  int uA2 = slotA0 + lane_u + 2 + hsel * IW;
-  int uB1 = uA1 + SLOT;
-  int uB2 = uA2 + SLOT;
-  int uS = slotA0 + lane_u + 2 * IW + 2 + hsel * SLOT;
+  int uA1, uA2, uB1, uB2, uS;  // set per chunk from the slots it lives in
 
   // De-phase the two waves that share a SIMD (waves w and w + 4), so that one's epilogue (vector ALU + stores, no matrix work) lies
   // beside the other's multiply instead of both storing at once with the matrix pipes idle:
@@ -291,29 +299,39 @@ __global__ __launch_bounds__((8 + STREAMS) * 64, 3) void conv_ring(const rsa_con
   if (RSA_RING_STAGGER) {
     if (STREAMS == 2) {
       if (g == 1)
-        for (int d = 0; d < nchunks * RSA_RING_STAGGER; ++d) __builtin_amdgcn_s_sleep(100);  // ~6400 cycles each
+        for (int d = 0; d < nq * RSA_RING_STAGGER; ++d) __builtin_amdgcn_s_sleep(100);  // ~6400 cycles each
     } else if (wave < 4) {
       __builtin_amdgcn_s_setprio(1);
     }
   }
 
   load_w(0);
-  uint32_t cnt = 0;  // chunks this stream has consumed
+  uint32_t kc = 0;  // half chunks this stream has consumed: half chunk k lives in slot slot_of(k), which it is the use_of(k)-th to use
+  auto slot_of = [&](uint32_t k) -> int { return (STREAMS == 2) ? 2 * g + (int)(k & 1) : (int)(k & 3); };
+  auto use_of = [&](uint32_t k) -> uint32_t { return (STREAMS == 2) ? (k >> 1) : (k >> 2); };
   for (int j = (STREAMS == 2 ? g : 0); j < ntw; j += STREAMS) {
-    for (int c = 0; c < nchunks; ++c, ++cnt) {
-      // slots of this chunk and how often each has been used before
-      const int sA = (STREAMS == 2) ? 2 * g : (int)(2 * (cnt & 1));
-      const int sB = sA + 1;
-      const uint32_t need = (STREAMS == 2) ? cnt + 1 : (cnt >> 1) + 1;
-      ring_wait(&f_full[sA], need, f_abort);
+    for (int c = 0; c < nq; ++c) {
+      const int sA = slot_of(kc), sB = HM ? sA : slot_of(kc + 1);
+      const uint32_t needA = use_of(kc) + 1, needB = use_of(kc + 1) + 1;
+      {
+        const int bA = sA * SLOT + lane_u, bB = sB * SLOT + lane_u;
+        uA1 = bA + hsel;
+        uA2 = bA + 2 + hsel * IW;
+        uB1 = bB + hsel;
+        uB2 = bB + 2 + hsel * IW;
+        // the pairing step reads tap (2,2) of half A (hsel 0) and of half B (hsel 1); in half mode the hsel-1 lanes read half A
+        // again and multiply zero weights (finite data: 0 * finite = 0)
+        uS = (hsel ? bB : bA) + 2 * IW + 2;
+      }
+      ring_wait(&f_full[sA], needA, f_abort);
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("" ::: "memory");
 
-      constexpr int NSTEP = 72;  // 9 K steps x 8 pixel tiles
+      constexpr int NSTEP = KSU * NPT;  // K steps x pixel tiles of one unit
       constexpr int DEPTH = 2;
       bf16x8 rh[DEPTH + 1], rl[DEPTH + 1];
       auto frag = [&](int i) -> int {  // unit of pixel-tile step i (compile-time i)
-        const int ks = i >> 3, pt = i & 7;
+        const int ks = i / NPT, pt = i % NPT;
         const int ptoff = (pt >> 1) * IW + (pt & 1) * 16;
         switch (ks) {
           case 0: return uA1 + ptoff;
@@ -334,16 +352,16 @@ __global__ __launch_bounds__((8 + STREAMS) * 64, 3) void conv_ring(const rsa_con
       }
       // one pixel-tile step: prefetch the fragments of step i + DEPTH, multiply step i (i is a compile-time constant after unrolling)
       auto step = [&](int i) {
-        const int ks = i >> 3, sp = i & 7;
+        const int ks = i / NPT, sp = i % NPT;
         if (sp == 0) {
 #pragma unroll
           for (int cc = 0; cc < CTW; ++cc)
 #pragma unroll
             for (int hl = 0; hl < 2; ++hl) wc[cc][hl] = wn[cc][hl];
-          const int s = c * 9 + ks;
+          const int s = c * KSU + ks;
           load_w(s + 1 < nks ? s + 1 : 0);  // next K step; after the last one: step 0 of the next tile
           if (ks == 5) {
-            // every read of half A has been consumed by an MFMA (the last ones in step 39): hand the slot back to the loader
+            // every read of half A has been consumed by an MFMA (the last ones in the step before): hand the slot back to the loader
             asm volatile("" ::: "memory");
             if (lane == 0) __hip_atomic_fetch_add(&f_free[sA], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
@@ -368,23 +386,24 @@ __global__ __launch_bounds__((8 + STREAMS) * 64, 3) void conv_ring(const rsa_con
         __builtin_amdgcn_sched_group_barrier(0x008, 3 * CTW, 0);
         __builtin_amdgcn_sched_barrier(0);
       };
-      constexpr int FIRST_B = 32 - DEPTH;  // the step whose prefetch is the first read of half B
+      if (HM) {
 #pragma unroll
-      for (int i = 0; i < FIRST_B; ++i) step(i);
-      ring_wait(&f_full[sB], need, f_abort);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("" ::: "memory");
+        for (int i = 0; i < NSTEP; ++i) step(i);
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(&f_free[sA], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        kc += 1;
+      } else {
+        constexpr int FIRST_B = 4 * NPT - DEPTH;  // the step whose prefetch is the first read of the pairing step (half B)
 #pragma unroll
-      for (int i = FIRST_B; i < NSTEP; ++i) step(i);
-      asm volatile("" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(&f_free[sB], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (STREAMS == 1) {  // the next chunk lives in the other pair of slots
-        const int d = (cnt & 1) ? -2 * SLOT : 2 * SLOT;
-        uA1 += d;
-        uA2 += d;
-        uB1 += d;
-        uB2 += d;
-        uS += d;
+        for (int i = 0; i < FIRST_B; ++i) step(i);
+        ring_wait(&f_full[sB], needB, f_abort);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = FIRST_B; i < NSTEP; ++i) step(i);
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(&f_free[sB], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        kc += 2;
       }
     }
     // ---- tile finished: epilogue (the loader is already streaming the next tile; the wave sharing this SIMD keeps multiplying) ----
@@ -400,8 +419,9 @@ __global__ __launch_bounds__((8 + STREAMS) * 64, 3) void conv_ring(const rsa_con
   }
 }
 
-template <int STREAMS, int UP, int OUTK>
+template <int SHAPE, int UP, int OUTK, int HM = 0>
 static int launch_ring(const rsa_conv_params& p, hipStream_t stream) {
+  constexpr int STREAMS = SHAPE == 2 ? 2 : 1;
   using R = RingGeo;
   const int tiles_x = (p.W + R::TW - 1) / R::TW;
   const int tiles_y = (p.H + R::TH - 1) / R::TH;
@@ -415,7 +435,7 @@ static int launch_ring(const rsa_conv_params& p, hipStream_t stream) {
   }();
   int gx = cus;  // one persistent workgroup per CU (the ring takes the whole LDS)
   if (gx > num_tiles) gx = (int)num_tiles;
-  hipLaunchKernelGGL((conv_ring<STREAMS, UP, OUTK>), dim3((unsigned)gx, 1, 1), dim3((8 + STREAMS) * 64), 0, stream, p);
+  hipLaunchKernelGGL((conv_ring<SHAPE, UP, OUTK, HM>), dim3((unsigned)gx, 1, 1), dim3((8 + STREAMS) * 64), 0, stream, p);
   return (int)hipGetLastError();
 }
 

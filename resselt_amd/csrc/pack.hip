@@ -9,6 +9,8 @@
 //        (lg & 1) of a 16-channel half (A = planes 4q, 4q+1; B = 4q+2, 4q+3) at one tap of the step's pair, selected by h = lg >> 1:
 //        s = 0,1,2: half A, tap (dy = s, dx = h)      s = 3: half A, tap (dy = h, dx = 2)      s = 4: tap (2,2) of half A (h = 0) / B (h = 1)
 //        s = 5,6,7: half B, tap (dy = s-5, dx = h)    s = 8: half B, tap (dy = h, dx = 2)
+//   layout RSA_WL_HALFPAIRS (conv_ring.h half mode, an odd number of half chunks): blob[half][s][ct][hl][lane][j], s = 0..4, plane
+//        2*half + (lg & 1):  s = 0,1,2: tap (dy = s, dx = h)   s = 3: tap (dy = h, dx = 2)   s = 4: tap (2,2) for h = 0, ZERO for h = 1
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -20,9 +22,9 @@ namespace rsa {
 typedef __attribute__((ext_vector_type(8))) __bf16 pk_bf16x8;
 
 __global__ void pack_weights_kernel(const float* __restrict__ w, int cout, int cin, int cin_planes, int ksize, int products, int layout, void* out) {
-  const int T = ksize * ksize;
+  const int T = layout == RSA_WL_HALFPAIRS ? 5 : ksize * ksize;                      // K steps per unit
   const int ct_total = (cout + 15) >> 4;
-  const int nq = (cin_planes + 3) >> 2;
+  const int nq = layout == RSA_WL_HALFPAIRS ? (cin_planes >> 1) : (cin_planes + 3) >> 2;  // units: half chunks / chunks
   const int nhl = products == 3 ? 2 : 1;
   const int64_t total = (int64_t)nq * T * ct_total * 64;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -35,7 +37,22 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int cout, int c
     const int lg = lane >> 4;
     const int co = 16 * ct + (lane & 15);
     int plane, ky, kx;
-    if (layout == RSA_WL_PAIRS) {
+    bool zero = false;
+    if (layout == RSA_WL_HALFPAIRS) {
+      const int h = lg >> 1;
+      plane = 2 * q + (lg & 1);
+      if (s < 3) {
+        ky = s;
+        kx = h;
+      } else if (s == 3) {
+        ky = h;
+        kx = 2;
+      } else {
+        ky = 2;
+        kx = 2;
+        zero = h != 0;
+      }
+    } else if (layout == RSA_WL_PAIRS) {
       const int h = lg >> 1;
       const int half = s < 4 ? 0 : (s == 4 ? h : 1);
       plane = 4 * q + 2 * half + (lg & 1);
@@ -60,7 +77,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int cout, int c
     for (int j = 0; j < 8; ++j) {
       const int ci = 8 * plane + j;
       float v = 0.f;
-      if (co < cout && ci < cin && plane < cin_planes) v = w[(((int64_t)co * cin + ci) * ksize + ky) * ksize + kx];
+      if (!zero && co < cout && ci < cin && plane < cin_planes) v = w[(((int64_t)co * cin + ci) * ksize + ky) * ksize + kx];
       const __bf16 hb = (__bf16)v;
       hi[j] = hb;
       lo[j] = (__bf16)(v - (float)hb);
@@ -78,12 +95,20 @@ extern "C" int rsa_pack_weights(const float* w_oihw, int32_t cout, int32_t cin, 
   if (w_oihw == nullptr || out == nullptr || cout < 1 || cin < 1 || cin_planes < 1) return rsa::set_error(RSA_E_ARG, "pack_weights: bad argument");
   if ((ksize != 1 && ksize != 3) || (products != 1 && products != 3)) return rsa::set_error(RSA_E_ARG, "pack_weights: ksize must be 1 or 3, products 1 or 3");
   if (cin > 8 * cin_planes) return rsa::set_error(RSA_E_ARG, "pack_weights: cin does not fit in cin_planes");
-  if (layout != rsa::RSA_WL_TAPS && layout != rsa::RSA_WL_PAIRS) return rsa::set_error(RSA_E_ARG, "pack_weights: unknown layout");
+  if (layout < rsa::RSA_WL_TAPS || layout > rsa::RSA_WL_HALFPAIRS) return rsa::set_error(RSA_E_ARG, "pack_weights: unknown layout");
   if (layout == rsa::RSA_WL_PAIRS && (ksize != 3 || products != 3 || (cin_planes & 3))) return rsa::set_error(RSA_E_UNSUPPORTED, "pack_weights: the tap-pair layout needs a 3x3, 3-product layer with whole 32-channel chunks");
+  if (layout == rsa::RSA_WL_HALFPAIRS && (ksize != 3 || products != 3 || (cin_planes & 1))) return rsa::set_error(RSA_E_UNSUPPORTED, "pack_weights: the half-chunk tap-pair layout needs a 3x3, 3-product layer with an even number of input planes");
   if ((uintptr_t)out & 15) return rsa::set_error(RSA_E_ALIGN, "pack_weights: out must be 16-byte aligned");
-  const int64_t total = (int64_t)((cin_planes + 3) / 4) * ksize * ksize * ((cout + 15) / 16) * 64;
+  const int64_t total = (layout == rsa::RSA_WL_HALFPAIRS ? (int64_t)(cin_planes / 2) * 5 : (int64_t)((cin_planes + 3) / 4) * ksize * ksize) * ((cout + 15) / 16) * 64;
   int64_t grid = (total + 255) / 256;
   if (grid > 4096) grid = 4096;
+  if (layout == rsa::RSA_WL_HALFPAIRS) {  // 5 K steps per half chunk < 9 per chunk: the rest of the (fixed-size) blob is defined as zero
+    const int64_t used = total * 2 * 16, size = (int64_t)((cin_planes + 3) / 4) * 9 * ((cout + 15) / 16) * 2 * 64 * 16;
+    if (size > used) {
+      const int rc0 = (int)hipMemsetAsync((char*)out + used, 0, (size_t)(size - used), (hipStream_t)stream);
+      if (rc0) return rsa::set_error(rc0, "pack_weights: memset failed");
+    }
+  }
   hipLaunchKernelGGL(rsa::pack_weights_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, cin_planes, ksize, products,
                      layout, out);
   const int rc = (int)hipGetLastError();

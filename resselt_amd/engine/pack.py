@@ -95,6 +95,33 @@ def pack_conv_weights_pairs(w: torch.Tensor, cin_planes: int) -> torch.Tensor:
     return out.contiguous()
 
 
+def pack_conv_weights_halfpairs(w: torch.Tensor, cin_planes: int) -> torch.Tensor:
+    """Layout 2 (half mode of the ring schedule: an odd number of 16-channel half chunks): packed[half][s 0..4][ct][hl][lane][j];
+    lane group lg reads plane 2*half + (lg & 1); s = 0,1,2: tap (ky = s, kx = h); s = 3: tap (ky = h, kx = 2); s = 4: tap (2,2) for
+    h = lg >> 1 == 0 and ZERO weights for h == 1.  The blob is allocated at the size of the chunked layouts; the tail stays zero."""
+    cout, cin, k, _ = w.shape
+    if k != 3 or cin_planes % 2 or cin > 8 * cin_planes:
+        raise ValueError('the half-chunk layout needs a 3x3 layer with an even number of input planes')
+    ct = (cout + 15) // 16
+    nh = cin_planes // 2
+    wp = torch.zeros((ct * 16, nh * 16, 3, 3), dtype=torch.float32, device=w.device)
+    wp[:cout, :cin] = w.to(torch.float32)
+    hi, lo = split_bf16(wp)
+    out = torch.zeros((nh, 5, ct, 2, 64, 8), dtype=torch.bfloat16, device=w.device)
+    for s in range(5):
+        for lg in range(4):
+            h = lg >> 1
+            if s == 4 and h:
+                continue
+            ky, kx = (s, h) if s < 3 else ((h, 2) if s == 3 else (2, 2))
+            for hl, src in enumerate((hi, lo)):
+                v = src[:, :, ky, kx].reshape(ct, 16, nh, 2, 8)[:, :, :, lg & 1, :].permute(2, 0, 1, 3)  # [nh, ct, 16 lanes, 8]
+                out[:, s, :, hl, lg * 16 : lg * 16 + 16, :] = v
+    full = torch.zeros(packed_weight_shape(cout, cin_planes, 3, 3), dtype=torch.bfloat16, device=w.device).reshape(-1)
+    full[: out.numel()] = out.reshape(-1)
+    return full
+
+
 def pad_bias(b: torch.Tensor | None, cout: int, device) -> torch.Tensor:
     """f32 bias padded to a multiple of 16 (zeros) so the kernel may read whole tiles."""
     out = torch.zeros(((cout + 15) // 16) * 16, dtype=torch.float32, device=device)

@@ -209,15 +209,21 @@ def test_argument_errors(device):
         ops.run_convs([p], device)
 
 
-@pytest.mark.parametrize('layout', [0, 1])
+@pytest.mark.parametrize('layout', [0, 1, 2])
 def test_pack_weights_kernel_matches_torch_packers(device, layout):
-    """rsa_pack_weights (csrc/pack.hip) against the torch restatement of both blob layouts (engine/pack.py)."""
+    """rsa_pack_weights (csrc/pack.hip) against the torch restatement of the three blob layouts (engine/pack.py)."""
     from resselt_amd.engine import pack
 
-    for cout, cin, planes, k, products in [(27, 61, 8, 3, 3), (64, 192, 24, 3, 3)] + ([] if layout else [(3, 64, 8, 3, 1), (720, 240, 30, 1, 3), (20, 11, 2, 3, 3)]):
+    cases = {
+        0: [(27, 61, 8, 3, 3), (64, 192, 24, 3, 3), (3, 64, 8, 3, 1), (720, 240, 30, 1, 3), (20, 11, 2, 3, 3)],
+        1: [(27, 61, 8, 3, 3), (64, 192, 24, 3, 3)],
+        2: [(48, 48, 6, 3, 3), (43, 77, 10, 3, 3), (20, 11, 2, 3, 3)],
+    }[layout]
+    ref = {0: lambda w, pl, pr: pack.pack_conv_weights(w, pl, pr), 1: lambda w, pl, pr: pack.pack_conv_weights_pairs(w, pl), 2: lambda w, pl, pr: pack.pack_conv_weights_halfpairs(w, pl)}[layout]
+    for cout, cin, planes, k, products in cases:
         w = _rand((cout, cin, k, k), cout + cin)
         got = ops.pack_weights_device(w.to(device), planes, products, layout).cpu()
-        want = pack.pack_conv_weights_pairs(w, planes) if layout else pack.pack_conv_weights(w, planes, products)
+        want = ref(w, planes, products)
         assert got.numel() == want.numel()
         assert torch.equal(got.view(torch.int16), want.reshape(-1).view(torch.int16)), (layout, cout, cin, k, products)
 
@@ -230,6 +236,9 @@ def test_pack_weights_kernel_matches_torch_packers(device, layout):
         (1, 192, 64, 270, 480, False),   # one-stream shape, 6 chunks, 510 tiles
         (1, 64, 64, 180, 260, True),     # nearest x2 folded into the loader (source 90 x 130)
         (1, 96, 24, 40, 70, False),      # cout not a multiple of 16: padded cout rows are zero weights
+        (2, 48, 48, 150, 260, False),    # three cout tiles, three half chunks: half mode (layout 2), the SPAN family's layers
+        (1, 80, 40, 70, 500, False),     # half mode with five half chunks, ragged cout
+        (1, 64, 48, 200, 333, False),    # three cout tiles over whole chunks
     ],
 )
 def test_conv_ring_schedule_whole_map(device, n, cin, cout, h, w, up):
@@ -243,7 +252,7 @@ def test_conv_ring_schedule_whole_map(device, n, cin, cout, h, w, up):
     out = tensors.Planes.empty(n, (cout + 7) // 8, h, w, device)
     of32 = tensors.empty_f32map(n, cout, h, w, device)
     p = ops.conv_params(wts, xin, h, w, upsample2x=up, out=out, out_f32=of32, act=L.ACT_LRELU, act_param=0.2)
-    assert p.w_layout == 1 and 'conv_ring' in L.conv_kernel_name(p)
+    assert p.w_layout == (2 if cin % 32 else 1) and 'conv_ring' in L.conv_kernel_name(p)
     before = L.ring_aborts()
     ops.run_convs([p], device)
     torch.cuda.synchronize()

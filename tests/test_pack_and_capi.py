@@ -119,3 +119,38 @@ def test_pair_layout_matches_index_formula():
         for lg in range(4):
             seen.add(pack.pair_layout_index(s, lg))
     assert len(seen) == 36 and seen == {(pl, ky, kx) for pl in range(4) for ky in range(3) for kx in range(3)}
+
+
+def test_halfpair_layout_matches_index_formula():
+    """Layout 2 (half mode of the ring schedule): five K steps per 16-channel half chunk, the fifth carrying tap (2,2) in lane groups
+    0-1 and zero weights in lane groups 2-3; every (plane, tap) of a half chunk exactly once."""
+    g = torch.Generator().manual_seed(6)
+    cout, cin, planes = 43, 45, 6
+    w = torch.randn((cout, cin, 3, 3), generator=g)
+    blob = pack.pack_conv_weights_halfpairs(w, planes)
+    assert blob.numel() == int(torch.tensor(pack.packed_weight_shape(cout, planes, 3, 3)).prod())
+    body = blob[: 3 * 5 * 3 * 2 * 64 * 8].reshape(3, 5, 3, 2, 64, 8)
+    assert blob[body.numel() :].abs().max() == 0
+    hi = _bf16(w)
+    lo = _bf16(w - hi.float())
+    seen = []
+    for s in range(5):
+        for lg in range(4):
+            h = lg >> 1
+            if s == 4 and h:
+                assert body[:, 4, :, :, lg * 16 : lg * 16 + 16].abs().max() == 0
+                continue
+            ky, kx = (s, h) if s < 3 else ((h, 2) if s == 3 else (2, 2))
+            seen.append((lg & 1, ky, kx))
+            for half in range(3):
+                for ct in range(3):
+                    for li in (0, 7, 15):
+                        co = 16 * ct + li
+                        for j in (0, 5):
+                            ci = 16 * half + 8 * (lg & 1) + j
+                            for hl, src in enumerate((hi, lo)):
+                                want = src[co, ci, ky, kx].item() if co < cout and ci < cin else 0.0
+                                assert body[half, s, ct, hl, lg * 16 + li, j].item() == want
+    assert len(seen) == 18 and set(seen) == {(pl, ky, kx) for pl in range(2) for ky in range(3) for kx in range(3)}
+    with pytest.raises(ValueError):
+        pack.pack_conv_weights_pairs(w, planes)  # whole chunks only

@@ -26,6 +26,8 @@ def family(name: str) -> str:
     name = name.replace('void ', '')
     if 'conv_ring<2' in name:
         return 'rsa::conv_ring<2,UP,0> (Cout<=32)'
+    if 'conv_ring<3' in name:
+        return 'rsa::conv_ring<3,UP,0> (Cout 33..48)'
     if 'conv_ring<1' in name:
         return 'rsa::conv_ring<1,UP,0> (Cout 49..64)'
     if 'conv_kernel_pp' in name:
