@@ -260,6 +260,67 @@ typedef struct rsa_window_attn_params {
 
 int rsa_window_attention(const rsa_window_attn_params* p, void* stream);
 
+/* ------------------------------------------------------------------------------------------- fused Swin block halves
+ * The two halves of SwinTransformerBlock.forward (resselt/archs/swinir/arch.py:295-335), each as ONE launch that reads the f32
+ * residual stream once and writes it once; everything between (LayerNorm output, q / k / v, attention output, the MLP's hidden map)
+ * stays in LDS and registers.  One workgroup = 64 tokens (a window, or 64 consecutive tokens for the MLP).
+ *
+ * rsa_swin_attn_block:  out = x + proj(window_attention(qkv(norm1(x))))      (:295-330 with WindowAttention.forward :133-173,
+ *                       torch.roll / window_partition / window_reverse / calculate_mask as index arithmetic)
+ * rsa_swin_mlp_block :  out = x + fc2(GELU(fc1(norm2(x))))                   (:331-335 with Mlp.forward :34-40)
+ *
+ * Weights are rsa_pack_weights blobs in layout 0 (ksize 1): wqkv over rows regrouped per head (row (which, head, d) with head_dim
+ * zero-padded to 32 and the q rows pre-scaled; cin_planes = ceil(C/8)), wproj over columns padded the same way (cin_planes =
+ * 4*heads), w1 [hidden][C] (cin_planes = ceil(C/8)), w2 [C][hidden] (cin_planes = ceil(hidden/8)).  Biases are f32 vectors padded
+ * with zeros to a multiple of 16.  bias_frag16: relative_position_bias_table[relative_position_index] in the accumulator order of
+ * 16x16 tiles, [head][key tile 4][query tile 4][lane 64][4] f32: lane l, element r <-> key 16*kt + 4*(l >> 4) + r, query
+ * 16*qt + (l & 15); key slots beyond window^2 carry -1e30.  Limits: C <= 256 (a multiple of 4), heads <= 8, head_dim <= 32,
+ * window <= 8, hidden <= 512; `out` may be `x` (in place). */
+typedef struct rsa_swin_attn_block_params {
+  int32_t batch;
+  int32_t H, W;            /* multiples of `window` */
+  int32_t C;               /* embedding width */
+  int32_t heads;
+  int32_t window;          /* <= 8 */
+  int32_t shift;           /* 0 or window/2 */
+  int32_t products;        /* 1 or 3 */
+  float eps;               /* LayerNorm epsilon */
+  const float* x;          /* f32 NCHW4c [N][ceil(C/4)][H][W][4] */
+  const float* gamma;      /* norm1 weight / bias, [C] */
+  const float* beta;
+  const void* wqkv;        /* packed, cout = 3*heads*32 */
+  const float* bqkv;       /* [3*heads*32] */
+  const float* bias_frag16;
+  const void* wproj;       /* packed, cout = C, cin_planes = 4*heads */
+  const float* bproj;      /* [C] padded to 16 */
+  float* out;              /* f32 NCHW4c, same shape as x */
+} rsa_swin_attn_block_params;
+
+int rsa_swin_attn_block(const rsa_swin_attn_block_params* p, void* stream);
+
+typedef struct rsa_swin_mlp_block_params {
+  int32_t batch;
+  int32_t H, W;
+  int32_t C;
+  int32_t hidden;
+  int32_t products;        /* 1 or 3 */
+  float eps;
+  const float* x;          /* f32 NCHW4c */
+  const float* gamma;      /* norm2 weight / bias, [C] */
+  const float* beta;
+  const void* w1;          /* packed, cout = hidden, cin_planes = ceil(C/8) */
+  const float* b1;         /* [hidden] padded to 16 */
+  const void* w2;          /* packed, cout = C, cin_planes = ceil(hidden/8) */
+  const float* b2;         /* [C] padded to 16 */
+  float* out;              /* f32 NCHW4c */
+  void* out_hi;            /* optional split-plane copy of the result (the input of the convolution that follows a block group) */
+  void* out_lo;
+  int64_t out_plane_stride; /* 16-byte units */
+  int64_t out_batch_stride;
+} rsa_swin_mlp_block_params;
+
+int rsa_swin_mlp_block(const rsa_swin_mlp_block_params* p, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------- DAT ops
  * Building blocks of the Dual Aggregation Transformer path (reference archs/dat/arch.py).  Tokens are pixels; every map is in
  * the split-plane layout [N][planes][H][W][8] (bf16 hi, optional lo).  Attention maps use the head-padded channel layout of

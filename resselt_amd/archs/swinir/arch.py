@@ -71,6 +71,25 @@ def bias_fragments(table: torch.Tensor, index: torch.Tensor, window: int) -> tor
     return out.contiguous()
 
 
+def bias_fragments16(table: torch.Tensor, index: torch.Tensor, window: int) -> torch.Tensor:
+    """The same gather in the accumulator order of 16x16 tiles (csrc/swin_block.hip): [heads][kt 4][qt 4][lane 64][4] f32,
+    lane l, element r  <->  key 16*kt + 4*(l >> 4) + r,  query 16*qt + (l & 15).  Padded keys get -1e30."""
+    n = window * window
+    heads = table.shape[1]
+    dense = torch.zeros((heads, 64, 64), dtype=torch.float32, device=table.device)  # [head][query][key]
+    dense[:, :, n:] = -1e30
+    dense[:, :n, :n] = table.to(torch.float32)[index.reshape(-1).long()].reshape(n, n, heads).permute(2, 0, 1)
+    lane = torch.arange(64, device=table.device)
+    r = torch.arange(4, device=table.device)
+    q_in = (lane & 15)[:, None].expand(64, 4)
+    k_in = 4 * (lane >> 4)[:, None] + r[None, :]
+    out = torch.empty((heads, 4, 4, 64, 4), dtype=torch.float32, device=table.device)
+    for kt in range(4):
+        for qt in range(4):
+            out[:, kt, qt] = dense[:, 16 * qt + q_in, 16 * kt + k_in]
+    return out.contiguous()
+
+
 def regroup_qkv(w: torch.Tensor, b: torch.Tensor | None, heads: int, scale_q: bool = True) -> tuple[torch.Tensor, torch.Tensor]:
     """[3C, C] -> [3*heads*32, C]: row (which, head, d) <- which*C + head*hd + d, zero rows for d >= hd; q rows scaled by hd^-0.5."""
     c3, c = w.shape
@@ -174,6 +193,9 @@ def swinir_param_shapes(in_ch, out_ch, embed_dim, depths, num_heads, window, mlp
 
 class SwinIR(EngineModule):
     hyperparameters = {}
+    # One launch per block half (csrc/swin_block.hip) where the shapes allow it; False = the layer-by-layer path (LayerNorm, Linear
+    # layers as k1 convolutions, rsa_window_attention), kept for widths the fused kernels do not take and for A/B runs.
+    fused_blocks = True
 
     def __init__(self, *, img_size=64, patch_size=1, in_chans=3, embed_dim=96, depths=(6, 6, 6, 6), num_heads=(6, 6, 6, 6), window_size=7,
                  mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1, ape=False,
@@ -238,6 +260,8 @@ class SwinIR(EngineModule):
                 lin(f'{b}.mlp.fc2')
                 W[f'{b}.bias_frag'] = bias_fragments(sd[f'{b}.attn.relative_position_bias_table'], sd[f'{b}.attn.relative_position_index'],
                                                      self.window_size)  # fmt: skip
+                W[f'{b}.bias_frag16'] = bias_fragments16(sd[f'{b}.attn.relative_position_bias_table'], sd[f'{b}.attn.relative_position_index'],
+                                                         self.window_size)  # fmt: skip
             resi_conv(f'layers.{i}.conv')
         ln('norm')
         resi_conv('conv_after_body')
@@ -311,9 +335,16 @@ class SwinIR(EngineModule):
         pool = [plan.f32map(n, C_, H, Wd) for _ in range(4)]
         a_pl = plan.planes(n, cp, H, Wd, with_lo)  # LayerNorm output / conv input
         max_heads = max(self.num_heads)
-        qkv_pl = plan.planes(n, 3 * max_heads * HEAD_PAD // 8, H, Wd, with_lo)
-        o_pl = plan.planes(n, max_heads * HEAD_PAD // 8, H, Wd, with_lo)
-        hid_pl = plan.planes(n, (hidden + 7) // 8, H, Wd, with_lo)
+
+        def can_fuse(heads):
+            return self.fused_blocks and C_ <= 256 and heads <= 8 and C_ // heads <= HEAD_PAD and hidden <= 512
+
+        if all(can_fuse(h) for h in self.num_heads):
+            qkv_pl = o_pl = hid_pl = None  # nothing between the residual stream and itself leaves the chip
+        else:
+            qkv_pl = plan.planes(n, 3 * max_heads * HEAD_PAD // 8, H, Wd, with_lo)
+            o_pl = plan.planes(n, max_heads * HEAD_PAD // 8, H, Wd, with_lo)
+            hid_pl = plan.planes(n, (hidden + 7) // 8, H, Wd, with_lo)
         body_pl = plan.planes(n, cp, H, Wd, with_lo)
         q4_a = plan.planes(n, (C_ // 4 + 7) // 8, H, Wd, with_lo) if self.resi == '3conv' else None
         q4_b = plan.planes(n, (C_ // 4 + 7) // 8, H, Wd, with_lo) if self.resi == '3conv' else None
@@ -341,6 +372,36 @@ class SwinIR(EngineModule):
             plan.call(lambda: L.check(lib.rsa_window_attention(C.byref(ap), C.c_void_p(ops.current_stream_ptr(dev))), 'rsa_window_attention'))
             plan.count_launches(1)
 
+        def attn_block(name, heads, shift, x_f32, out_f32):
+            """norm1 -> qkv -> window attention -> proj -> + shortcut in one launch (arch.py:295-330)."""
+            g, be = W[f'{name}.norm1']
+            qkv, proj = W[f'{name}.attn.qkv'], W[f'{name}.attn.proj']
+            ap = L.SwinAttnBlockParams()
+            ap.batch, ap.H, ap.W, ap.C, ap.heads, ap.window, ap.shift, ap.products, ap.eps = n, H, Wd, C_, heads, win, shift, products, 1e-5
+            ap.x, ap.gamma, ap.beta = x_f32.data_ptr(), g.data_ptr(), be.data_ptr()
+            ap.wqkv, ap.bqkv = qkv.packed_for(0).data_ptr(), qkv.bias.data_ptr()
+            ap.bias_frag16 = W[f'{name}.bias_frag16'].data_ptr()
+            ap.wproj, ap.bproj = proj.packed_for(0).data_ptr(), proj.bias.data_ptr()
+            ap.out = out_f32.data_ptr()
+            plan.call(lambda: L.check(lib.rsa_swin_attn_block(C.byref(ap), C.c_void_p(ops.current_stream_ptr(dev))), 'rsa_swin_attn_block'))
+            plan.count_launches(1)
+
+        def mlp_block(name, x_f32, out_f32, out_planes=None):
+            """norm2 -> fc1 -> GELU -> fc2 -> + shortcut in one launch (arch.py:331-335)."""
+            g, be = W[f'{name}.norm2']
+            fc1, fc2 = W[f'{name}.mlp.fc1'], W[f'{name}.mlp.fc2']
+            mp = L.SwinMlpBlockParams()
+            mp.batch, mp.H, mp.W, mp.C, mp.hidden, mp.products, mp.eps = n, H, Wd, C_, hidden, products, 1e-5
+            mp.x, mp.gamma, mp.beta = x_f32.data_ptr(), g.data_ptr(), be.data_ptr()
+            mp.w1, mp.b1 = fc1.packed_for(0).data_ptr(), fc1.bias.data_ptr()
+            mp.w2, mp.b2 = fc2.packed_for(0).data_ptr(), fc2.bias.data_ptr()
+            mp.out = out_f32.data_ptr()
+            if out_planes is not None:
+                mp.out_hi, mp.out_lo = out_planes.hi_ptr(), out_planes.lo_ptr()
+                mp.out_plane_stride, mp.out_batch_stride = out_planes.plane_stride, out_planes.batch_stride
+            plan.call(lambda: L.check(lib.rsa_swin_mlp_block(C.byref(mp), C.c_void_p(ops.current_stream_ptr(dev))), 'rsa_swin_mlp_block'))
+            plan.count_launches(1)
+
         def resi_conv(name, src_planes, res, out_f32=None, out_planes=None):
             """1conv / 3conv tail (arch.py:562-574) + the residual add that follows it."""
             if self.resi == '1conv':
@@ -365,17 +426,22 @@ class SwinIR(EngineModule):
             for j in range(depth):
                 b = f'layers.{i}.residual_group.blocks.{j}'
                 shift = 0 if j % 2 == 0 else win // 2
-                layernorm(f'{b}.norm1', cur, out_planes=a_pl)
-                plan.conv(ops.conv_params(W[f'{b}.attn.qkv'], a_pl, H, Wd, cin_planes=cp, out=qkv_pl))
-                attention(b, heads, shift)
-                x1 = free.pop()
-                plan.conv(ops.conv_params(W[f'{b}.attn.proj'], o_pl, H, Wd, cin_planes=hp, res1=cur, alpha=1.0, out_f32=x1))
-                layernorm(f'{b}.norm2', x1, out_planes=a_pl)
-                plan.conv(ops.conv_params(W[f'{b}.mlp.fc1'], a_pl, H, Wd, cin_planes=cp, act=L.ACT_GELU, out=hid_pl))
-                x2 = free.pop()
                 last = j == depth - 1
-                plan.conv(ops.conv_params(W[f'{b}.mlp.fc2'], hid_pl, H, Wd, cin_planes=(hidden + 7) // 8, res1=x1, alpha=1.0, out_f32=x2,
-                                          out=body_pl if last else None))  # fmt: skip
+                x1 = free.pop()
+                if can_fuse(heads):
+                    attn_block(b, heads, shift, cur, x1)
+                    x2 = free.pop()
+                    mlp_block(b, x1, x2, body_pl if last else None)
+                else:
+                    layernorm(f'{b}.norm1', cur, out_planes=a_pl)
+                    plan.conv(ops.conv_params(W[f'{b}.attn.qkv'], a_pl, H, Wd, cin_planes=cp, out=qkv_pl))
+                    attention(b, heads, shift)
+                    plan.conv(ops.conv_params(W[f'{b}.attn.proj'], o_pl, H, Wd, cin_planes=hp, res1=cur, alpha=1.0, out_f32=x1))
+                    layernorm(f'{b}.norm2', x1, out_planes=a_pl)
+                    plan.conv(ops.conv_params(W[f'{b}.mlp.fc1'], a_pl, H, Wd, cin_planes=cp, act=L.ACT_GELU, out=hid_pl))
+                    x2 = free.pop()
+                    plan.conv(ops.conv_params(W[f'{b}.mlp.fc2'], hid_pl, H, Wd, cin_planes=(hidden + 7) // 8, res1=x1, alpha=1.0, out_f32=x2,
+                                              out=body_pl if last else None))  # fmt: skip
                 if cur is not rstb_in and cur is not first:
                     free.append(cur)
                 free.append(x1)

@@ -1,0 +1,528 @@
+// swin_block.hip — the two halves of a Swin transformer block, one launch each:
+//
+//   rsa_swin_attn_block   out = x + proj(window_attention(qkv(norm1(x))))   (reference archs/swinir/arch.py:295-330, :133-173)
+//   rsa_swin_mlp_block    out = x + fc2(GELU(fc1(norm2(x))))                (reference archs/swinir/arch.py:331-335, :34-40)
+//
+// The layer-by-layer path (rsa_layernorm, gemm_k1, rsa_window_attention) moves 21 KB per token and block through HBM in the split
+// layouts; here a workgroup keeps its 64 tokens on chip from the f32 residual stream in to the f32 residual stream out (1.9 KB per
+// token and half block).  The workgroup is token-stationary, the weights stream from L2 (every workgroup of a launch reads the same
+// 0.4–0.9 MB, which the 4 MiB L2 of each XCD holds), each wave owning its own output channels so that no weight fragment is fetched
+// twice by a workgroup:
+//
+//   LayerNorm        lane (j, tok8) = token 8*row + tok8, planes j, j+8, ...: statistics by lane shuffles, result as split planes
+//                    [plane][64 tokens][8 ch] (hi image, lo image) in LDS -- the B-fragment image of v_mfma_f32_16x16x32_bf16
+//   Linear layers    gemm_tile: a wave multiplies CTW cout tiles x 4 token tiles over the whole K; B fragments by ds_read_b128
+//                    (conflict-free: plane stride 1 KiB), A fragments by buffer_load from the packed blob one K chunk ahead
+//   attention        wave = head.  q and k come out of the qkv multiply as D fragments [channel][token]; v is multiplied with the
+//                    operands swapped, D [token][channel].  A D fragment pair is a valid MFMA operand when both sides of the
+//                    contraction use the same slot order (slot j of lane group lg <-> index 16*(j>>2) + 4*lg + (j&3)), so
+//                    S^T = K Q^T, the softmax and O^T = V^T P^T run entirely in the wave's registers: no LDS, no transposes.
+//   hand-over        attention output / hidden map back to LDS as split planes (lane-pair exchange, 16-byte units) over the
+//                    LayerNorm image, workgroup barrier, next multiply.
+#include "conv_common.h"
+
+namespace rsa {
+
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+constexpr int SB_TOK = 64;  // tokens per workgroup
+
+// LayerNorm of the workgroup's tokens into the LDS plane image.  pix_of(t): pixel of token t in its image, or -1 (no such token:
+// the image gets zeros).  Planes [ceil(C/8), planes_pad) are zeroed (K padding of the multiply that follows).
+template <int PROD, typename PixOf>
+__device__ __forceinline__ void ln_to_lds(uint4* lds, int lo0, int planes_pad, const f32x4* x_img, int64_t HW, int C, const float* gamma,
+                                          const float* beta, float eps, int wave, int nwaves, int lane, PixOf pix_of) {
+  const int j = lane >> 3, tok8 = lane & 7;
+  const int p4 = (C + 3) >> 2;
+  const float inv_c = 1.f / (float)C;
+  for (int row = wave; row < 8; row += nwaves) {
+    const int t = row * 8 + tok8;
+    const int64_t pix = pix_of(t);
+    f32x4 v[4][2];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int g = (j + 8 * i) * 2 + h;
+        v[i][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (pix >= 0 && g < p4) v[i][h] = x_img[(int64_t)g * HW + pix];  // C % 4 == 0: a group is whole or absent
+        sum += (v[i][h][0] + v[i][h][1]) + (v[i][h][2] + v[i][h][3]);
+      }
+    sum += __shfl_xor(sum, 8);
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * inv_c;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int g = (j + 8 * i) * 2 + h;
+        if (g < p4) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float d = v[i][h][r] - mean;
+            var += d * d;
+          }
+        }
+      }
+    var += __shfl_xor(var, 8);
+    var += __shfl_xor(var, 16);
+    var += __shfl_xor(var, 32);
+    const float rstd = rsqrtf(var * inv_c + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pl = j + 8 * i;
+      if (pl >= planes_pad) continue;
+      uint32_t h[4], l[4];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int g = pl * 2 + hh;
+        f32x4 y = {0.f, 0.f, 0.f, 0.f};
+        if (pix >= 0 && g < p4) {
+          const f32x4 ga = ((const f32x4*)gamma)[g], be = ((const f32x4*)beta)[g];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) y[r] = (v[i][hh][r] - mean) * rstd * ga[r] + be[r];
+        }
+        split2(y[0], y[1], h[2 * hh], l[2 * hh]);
+        split2(y[2], y[3], h[2 * hh + 1], l[2 * hh + 1]);
+      }
+      lds[pl * SB_TOK + t] = make_uint4(h[0], h[1], h[2], h[3]);
+      if (PROD == 3) lds[lo0 + pl * SB_TOK + t] = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+  }
+}
+
+// acc[c][pt] += W[cout tile c][K] . X[K][token tile pt]  over nk chunks of 32 channels.  X: LDS plane image (hi at 0, lo at lo0);
+// W: packed blob (layout 0, ksize 1: [chunk][cout tile][hi|lo][lane][8]) behind the buffer resource rw, woff[c] = byte offset of
+// this lane's fragment of cout tile c inside a chunk, or 0xFFFFFFFF (a tile beyond the layer: the range check of the buffer load
+// looks at the vector offset alone and returns zeros).  SWAP: tokens on the MFMA rows (D[token][channel]) instead of the columns.
+template <int PROD, int CTW, int NPT, bool SWAP>
+__device__ __forceinline__ void gemm_tile(f32x4 (&acc)[CTW][NPT], const uint4* lds, int lo0, int nk, const __amdgpu_buffer_rsrc_t rw,
+                                          const uint32_t (&woff)[CTW], uint32_t wstep, int li, int lg) {
+  constexpr int NHL = PROD == 3 ? 2 : 1;
+  bf16x8 wn[CTW][NHL];
+  auto load_w = [&](int kc) {
+#pragma unroll
+    for (int c = 0; c < CTW; ++c)
+#pragma unroll
+      for (int hl = 0; hl < NHL; ++hl)
+        wn[c][hl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, woff[c], (uint32_t)kc * wstep + (uint32_t)hl * 1024u, 0));
+  };
+  load_w(0);
+  const int bu = lg * SB_TOK + li;
+#pragma unroll 1
+  for (int kc = 0; kc < nk; ++kc) {
+    bf16x8 wc[CTW][NHL];
+#pragma unroll
+    for (int c = 0; c < CTW; ++c)
+#pragma unroll
+      for (int hl = 0; hl < NHL; ++hl) wc[c][hl] = wn[c][hl];
+    load_w(kc + 1 < nk ? kc + 1 : kc);  // one chunk ahead (the last iteration re-reads its own chunk: no branch around the loads)
+    bf16x8 bh[NPT], bl[NPT];
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) {
+      const int u = kc * 4 * SB_TOK + bu + 16 * pt;
+      bh[pt] = __builtin_bit_cast(bf16x8, lds[u]);
+      if (PROD == 3) bl[pt] = __builtin_bit_cast(bf16x8, lds[lo0 + u]);
+    }
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+      for (int c = 0; c < CTW; ++c) {
+        // products in increasing magnitude: w_lo*x_hi, w_hi*x_lo, w_hi*x_hi
+        if (PROD == 3) {
+          acc[c][pt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[pt], wc[c][NHL - 1], acc[c][pt], 0, 0, 0)
+                            : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[c][NHL - 1], bh[pt], acc[c][pt], 0, 0, 0);
+          acc[c][pt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[pt], wc[c][0], acc[c][pt], 0, 0, 0)
+                            : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[c][0], bl[pt], acc[c][pt], 0, 0, 0);
+        }
+        acc[c][pt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[pt], wc[c][0], acc[c][pt], 0, 0, 0)
+                          : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[c][0], bh[pt], acc[c][pt], 0, 0, 0);
+      }
+  }
+}
+
+// eight f32 values -> the bf16 hi fragment and (PROD 3) the residual fragment
+__device__ __forceinline__ void frag_of(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
+  uint32_t h[4], l[4];
+  split2(a[0], a[1], h[0], l[0]);
+  split2(a[2], a[3], h[1], l[1]);
+  split2(b[0], b[1], h[2], l[2]);
+  split2(b[2], b[3], h[3], l[3]);
+  hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+  lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+}
+
+template <int PROD>
+__device__ __forceinline__ f32x4 mfma3(const bf16x8 ah, const bf16x8 al, const bf16x8 bh, const bf16x8 bl, f32x4 c) {
+  if (PROD == 3) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+  }
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+}
+
+// Two D fragments of the token-tile pair (2k, 2k+1) of one 16-channel tile -> the 16-byte plane units of plane 2*ct + (lg >> 1):
+// the even lane group ends up with the full unit of token tile 2k, the odd one with that of 2k+1 (v_permlane16_swap, as the
+// convolution epilogue).  Returns the token tile this lane stores.
+__device__ __forceinline__ void pair_units(const f32x4 a, const f32x4 b, uint4& uh, uint4& ul) {
+  uint32_t h[2][2], l[2][2];
+  split2(a[0], a[1], h[0][0], l[0][0]);
+  split2(a[2], a[3], h[0][1], l[0][1]);
+  split2(b[0], b[1], h[1][0], l[1][0]);
+  split2(b[2], b[3], h[1][1], l[1][1]);
+  const u32x2 h0 = __builtin_amdgcn_permlane16_swap(h[0][0], h[1][0], false, false);
+  const u32x2 h1 = __builtin_amdgcn_permlane16_swap(h[0][1], h[1][1], false, false);
+  const u32x2 l0 = __builtin_amdgcn_permlane16_swap(l[0][0], l[1][0], false, false);
+  const u32x2 l1 = __builtin_amdgcn_permlane16_swap(l[0][1], l[1][1], false, false);
+  uh = make_uint4(h0.x, h1.x, h0.y, h1.y);
+  ul = make_uint4(l0.x, l1.x, l0.y, l1.y);
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const void* w, int64_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (uint32_t)bytes, 0x00020000);
+}
+
+// ------------------------------------------------------------------------------------------------ attention half
+// One workgroup = one (shifted) window; `heads` waves, wave = head.
+template <int PROD>
+__global__ __launch_bounds__(512) void swin_attn_block_kernel(const rsa_swin_attn_block_params p) {
+  constexpr int XPL = 32;  // planes of the LDS image (256 channels)
+  constexpr int LO0 = XPL * SB_TOK;
+  constexpr int NHL = PROD == 3 ? 2 : 1;
+  __shared__ uint4 s_x[2 * XPL * SB_TOK];  // 64 KB: LayerNorm image, later the attention output image
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int heads = p.heads;
+  const int li = lane & 15, lg = lane >> 4;
+  const int w = p.window, ntok = w * w;
+  const int nwx = p.W / w, nwy = p.H / w;
+  const int win = (int)blockIdx.x;
+  const int wx = win % nwx, wy = (win / nwx) % nwy, n = win / (nwx * nwy);
+  const int64_t HW = (int64_t)p.H * p.W;
+  const int p4 = (p.C + 3) >> 2;
+  const int planes = (p.C + 7) >> 3;
+  const int nk = (planes + 3) >> 2;
+
+  // pixel of window token t after the cyclic shift (torch.roll(-s), partition; the result is rolled back, so a token's output
+  // lands on the pixel it was read from)
+  auto token_pix = [&](int t) -> int64_t {
+    if (t >= ntok) return -1;
+    const int ty = t / w, tx = t - ty * w;
+    int py = wy * w + ty + p.shift, px = wx * w + tx + p.shift;
+    if (py >= p.H) py -= p.H;
+    if (px >= p.W) px -= p.W;
+    return (int64_t)py * p.W + px;
+  };
+  const f32x4* x_img = (const f32x4*)p.x + (int64_t)n * p4 * HW;
+  ln_to_lds<PROD>(s_x, LO0, 4 * nk, x_img, HW, p.C, p.gamma, p.beta, p.eps, wave, heads, lane, token_pix);
+  __syncthreads();
+
+  const int head = wave;
+  const int ct_qkv = 3 * heads * 2;
+  const __amdgpu_buffer_rsrc_t rq = weight_rsrc(p.wqkv, (int64_t)nk * ct_qkv * NHL * 1024);
+  const uint32_t qstep = (uint32_t)ct_qkv * NHL * 1024u;
+  const f32x4* bqkv4 = (const f32x4*)p.bqkv;
+
+  // ---- q and k of this head: D[channel 16*dt + 4*lg + r][token 16*tt + li] ----
+  bf16x8 qh[4], ql[4], kh[4], kl[4];
+  {
+    f32x4 a[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) a[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint32_t woff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) woff[c] = (uint32_t)(((((c >> 1) * heads + head) * 2 + (c & 1)) * NHL * 64 + lane) * 16);
+    gemm_tile<PROD, 4, 4, false>(a, s_x, LO0, nk, rq, woff, qstep, li, lg);
+    f32x4 b[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) b[c] = bqkv4[(((c >> 1) * heads + head) * 2 + (c & 1)) * 4 + lg];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      frag_of(a[0][tt] + b[0], a[1][tt] + b[1], qh[tt], ql[tt]);
+      frag_of(a[2][tt] + b[2], a[3][tt] + b[3], kh[tt], kl[tt]);
+    }
+  }
+  // ---- v of this head with the operands swapped: D[token 16*tt + 4*lg + r][channel 16*dt + li] ----
+  bf16x8 vh[2][2], vl[2][2];  // [dt][key tile pair]
+  {
+    f32x4 a[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) a[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint32_t woff[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) woff[c] = (uint32_t)((((2 * heads + head) * 2 + c) * NHL * 64 + lane) * 16);
+    gemm_tile<PROD, 2, 4, true>(a, s_x, LO0, nk, rq, woff, qstep, li, lg);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const float bv = p.bqkv[((2 * heads + head) * 2 + dt) * 16 + li];
+#pragma unroll
+      for (int kp = 0; kp < 2; ++kp) frag_of(a[dt][2 * kp] + bv, a[dt][2 * kp + 1] + bv, vh[dt][kp], vl[dt][kp]);
+    }
+  }
+  __syncthreads();  // every wave has read the LayerNorm image for the last time: the attention output may overwrite it
+
+  // ---- attention of this head, in registers ----
+  const bool masked = p.shift > 0 && (wy == nwy - 1 || wx == nwx - 1);
+  auto region = [&](int t) -> int {  // img_mask region id of a window token on the SHIFTED grid (arch.py:268-293)
+    const int tt = t < ntok ? t : 0;
+    const int ty = tt / w, tx = tt - ty * w;
+    const int gy = wy * w + ty, gx = wx * w + tx;
+    const int ry = gy < p.H - w ? 0 : (gy < p.H - p.shift ? 1 : 2);
+    const int rx = gx < p.W - w ? 0 : (gx < p.W - p.shift ? 1 : 2);
+    return ry * 3 + rx;
+  };
+  f32x4 o[2][4];  // O^T: D[channel 16*dt + 4*lg + r][query 16*qt + li]
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    f32x4 s[4];  // S^T: D[key 16*kt + 4*lg + r][query 16*qt + li]
+    const int rq_ = masked ? region(16 * qt + li) : 0;
+    float m = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      s[kt] = mfma3<PROD>(kh[kt], kl[kt], qh[qt], ql[qt], (f32x4){0.f, 0.f, 0.f, 0.f});
+      const f32x4 bf = ((const f32x4*)p.bias_frag16)[(((int64_t)head * 4 + kt) * 4 + qt) * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = s[kt][r] + bf[r];
+        if (masked && region(16 * kt + 4 * lg + r) != rq_) v += -100.f;
+        s[kt][r] = v;
+        m = fmaxf(m, v);
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = expf(s[kt][r] - m);
+        s[kt][r] = e;
+        l += e;
+      }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv_l = 1.f / l;
+    bf16x8 ph[2], pl[2];
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp) frag_of(s[2 * kp], s[2 * kp + 1], ph[kp], pl[kp]);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kp = 0; kp < 2; ++kp) acc = mfma3<PROD>(vh[dt][kp], vl[dt][kp], ph[kp], pl[kp], acc);
+      o[dt][qt] = acc * inv_l;
+    }
+  }
+  // ---- attention output -> LDS planes [head*4 + dt*2 + (lg >> 1)][token] ----
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      uint4 uh, ul;
+      pair_units(o[dt][2 * k], o[dt][2 * k + 1], uh, ul);
+      const int u = (head * 4 + dt * 2 + (lg >> 1)) * SB_TOK + 16 * (2 * k + (lg & 1)) + li;
+      s_x[u] = uh;
+      if (PROD == 3) s_x[LO0 + u] = ul;
+    }
+  __syncthreads();
+
+  // ---- proj + bias + shortcut -> residual stream ----
+  {
+    const int ct_c = (p.C + 15) >> 4;
+    const __amdgpu_buffer_rsrc_t rp = weight_rsrc(p.wproj, (int64_t)heads * ct_c * NHL * 1024);
+    f32x4 a[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) a[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint32_t woff[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) woff[c] = (2 * wave + c < ct_c) ? (uint32_t)(((2 * wave + c) * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
+    gemm_tile<PROD, 2, 4, false>(a, s_x, LO0, heads, rp, woff, (uint32_t)ct_c * NHL * 1024u, li, lg);
+    f32x4* o_img = (f32x4*)p.out + (int64_t)n * p4 * HW;
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+      const int64_t pix = token_pix(16 * pt + li);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int g = (2 * wave + c) * 4 + lg;
+        if (pix < 0 || g >= p4) continue;
+        const f32x4 b = ((const f32x4*)p.bproj)[g];
+        const f32x4 r = x_img[(int64_t)g * HW + pix];
+        o_img[(int64_t)g * HW + pix] = a[c][pt] + b + r;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ MLP half
+// One workgroup (8 waves) = 64 consecutive tokens of one image.
+template <int PROD>
+__global__ __launch_bounds__(512) void swin_mlp_block_kernel(const rsa_swin_mlp_block_params p) {
+  constexpr int HPL = 64;  // planes of the LDS image (512 hidden channels)
+  constexpr int LO0 = HPL * SB_TOK;
+  constexpr int NHL = PROD == 3 ? 2 : 1;
+  __shared__ uint4 s_h[2 * HPL * SB_TOK];  // 128 KB: LayerNorm image (planes 0..31), then the hidden map
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int64_t HW = (int64_t)p.H * p.W;
+  const int tiles_img = (int)((HW + SB_TOK - 1) / SB_TOK);
+  const int n = (int)blockIdx.x / tiles_img;
+  const int64_t t0 = (int64_t)((int)blockIdx.x % tiles_img) * SB_TOK;
+  const int p4 = (p.C + 3) >> 2;
+  const int planes = (p.C + 7) >> 3;
+  const int nk1 = (planes + 3) >> 2;
+  const int hplanes = (p.hidden + 7) >> 3;
+  const int nk2 = (hplanes + 3) >> 2;
+  const int ct_h = (p.hidden + 15) >> 4, ct_c = (p.C + 15) >> 4;
+
+  auto token_pix = [&](int t) -> int64_t { return t0 + t < HW ? t0 + t : -1; };
+  const f32x4* x_img = (const f32x4*)p.x + (int64_t)n * p4 * HW;
+  ln_to_lds<PROD>(s_h, LO0, 4 * nk1, x_img, HW, p.C, p.gamma, p.beta, p.eps, wave, 8, lane, token_pix);
+  __syncthreads();
+
+  // ---- fc1 + GELU: wave owns hidden cout tiles 4*wave .. +3 ----
+  f32x4 a1[4][4];
+  {
+    const __amdgpu_buffer_rsrc_t r1 = weight_rsrc(p.w1, (int64_t)nk1 * ct_h * NHL * 1024);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) a1[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint32_t woff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) woff[c] = (4 * wave + c < ct_h) ? (uint32_t)(((4 * wave + c) * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
+    gemm_tile<PROD, 4, 4, false>(a1, s_h, LO0, nk1, r1, woff, (uint32_t)ct_h * NHL * 1024u, li, lg);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ct = 4 * wave + c;
+      f32x4 b = {0.f, 0.f, 0.f, 0.f};
+      if (ct < ct_h) b = ((const f32x4*)p.b1)[ct * 4 + lg];
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a1[c][pt][r] = act_apply<AC_GELU>(a1[c][pt][r] + b[r], RSA_ACT_GELU, 0.f);  // tiles beyond the layer: GELU(0) = 0
+    }
+  }
+  __syncthreads();  // every wave has read the LayerNorm image for the last time
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int ct = 4 * wave + c;
+    if (ct >= 2 * nk2) continue;  // planes of the K padding are written (as zeros) too
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      uint4 uh, ul;
+      pair_units(a1[c][2 * k], a1[c][2 * k + 1], uh, ul);
+      const int u = (2 * ct + (lg >> 1)) * SB_TOK + 16 * (2 * k + (lg & 1)) + li;
+      s_h[u] = uh;
+      if (PROD == 3) s_h[LO0 + u] = ul;
+    }
+  }
+  __syncthreads();
+
+  // ---- fc2 + bias + shortcut: wave owns cout tiles 2*wave, 2*wave + 1 ----
+  {
+    const __amdgpu_buffer_rsrc_t r2 = weight_rsrc(p.w2, (int64_t)nk2 * ct_c * NHL * 1024);
+    f32x4 a[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) a[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint32_t woff[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) woff[c] = (2 * wave + c < ct_c) ? (uint32_t)(((2 * wave + c) * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
+    gemm_tile<PROD, 2, 4, false>(a, s_h, LO0, nk2, r2, woff, (uint32_t)ct_c * NHL * 1024u, li, lg);
+    f32x4* o_img = (f32x4*)p.out + (int64_t)n * p4 * HW;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int ct = 2 * wave + c;
+      const int g = ct * 4 + lg;
+      f32x4 b = {0.f, 0.f, 0.f, 0.f};
+      if (g < p4) b = ((const f32x4*)p.b2)[g];
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) {
+        const int64_t pix = token_pix(16 * pt + li);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pix >= 0 && g < p4) {
+          v = a[c][pt] + b + x_img[(int64_t)g * HW + pix];
+          o_img[(int64_t)g * HW + pix] = v;
+        }
+        a[c][pt] = v;
+      }
+      if (p.out_hi != nullptr) {  // wave-uniform: every lane takes part in the exchange
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          uint4 uh, ul;
+          pair_units(a[c][2 * k], a[c][2 * k + 1], uh, ul);
+          const int pl = 2 * ct + (lg >> 1);
+          const int64_t pix = token_pix(16 * (2 * k + (lg & 1)) + li);
+          if (pix >= 0 && pl < planes) {
+            const int64_t u = (int64_t)n * p.out_batch_stride + (int64_t)pl * p.out_plane_stride + pix;
+            ((uint4*)p.out_hi)[u] = uh;
+            if (p.out_lo != nullptr) ((uint4*)p.out_lo)[u] = ul;
+          }
+        }
+      }
+    }
+  }
+}
+
+static bool aligned16(const void* a) { return ((uintptr_t)a & 15) == 0; }
+
+}  // namespace rsa
+
+extern "C" int rsa_swin_attn_block(const rsa_swin_attn_block_params* p, void* stream) {
+  using namespace rsa;
+  if (p == nullptr) return set_error(RSA_E_ARG, "swin_attn_block: null params");
+  if (p->batch < 1 || p->H < 1 || p->W < 1 || p->C < 4 || p->heads < 1) return set_error(RSA_E_ARG, "swin_attn_block: bad geometry");
+  if (p->window < 1 || p->window > 8) return set_error(RSA_E_UNSUPPORTED, "swin_attn_block: window must be 1..8 (<= 64 tokens)");
+  if (p->H % p->window || p->W % p->window) return set_error(RSA_E_ARG, "swin_attn_block: H and W must be multiples of the window");
+  if (p->shift < 0 || p->shift >= p->window) return set_error(RSA_E_ARG, "swin_attn_block: shift must be in [0, window)");
+  if (p->products != 1 && p->products != 3) return set_error(RSA_E_UNSUPPORTED, "swin_attn_block: products must be 1 or 3");
+  if (p->C > 256 || (p->C & 3)) return set_error(RSA_E_UNSUPPORTED, "swin_attn_block: C must be a multiple of 4, at most 256");
+  if (p->heads > 8 || p->C % p->heads || p->C / p->heads > 32) return set_error(RSA_E_UNSUPPORTED, "swin_attn_block: at most 8 heads of at most 32 channels");
+  if (!p->x || !p->gamma || !p->beta || !p->wqkv || !p->bqkv || !p->bias_frag16 || !p->wproj || !p->bproj || !p->out)
+    return set_error(RSA_E_ARG, "swin_attn_block: null pointer");
+  if (!aligned16(p->x) || !aligned16(p->gamma) || !aligned16(p->beta) || !aligned16(p->wqkv) || !aligned16(p->bqkv) || !aligned16(p->bias_frag16) ||
+      !aligned16(p->wproj) || !aligned16(p->bproj) || !aligned16(p->out))
+    return set_error(RSA_E_ALIGN, "swin_attn_block: pointers must be 16-byte aligned");
+  const int64_t windows = (int64_t)p->batch * (p->H / p->window) * (p->W / p->window);
+  if (windows > 0x7fffffff) return set_error(RSA_E_UNSUPPORTED, "swin_attn_block: too many windows");
+  if (p->products == 3)
+    hipLaunchKernelGGL(swin_attn_block_kernel<3>, dim3((unsigned)windows), dim3(64 * p->heads), 0, (hipStream_t)stream, *p);
+  else
+    hipLaunchKernelGGL(swin_attn_block_kernel<1>, dim3((unsigned)windows), dim3(64 * p->heads), 0, (hipStream_t)stream, *p);
+  const int rc = (int)hipGetLastError();
+  return rc ? set_error(rc, "swin_attn_block: launch failed") : RSA_OK;
+}
+
+extern "C" int rsa_swin_mlp_block(const rsa_swin_mlp_block_params* p, void* stream) {
+  using namespace rsa;
+  if (p == nullptr) return set_error(RSA_E_ARG, "swin_mlp_block: null params");
+  if (p->batch < 1 || p->H < 1 || p->W < 1 || p->C < 4 || p->hidden < 1) return set_error(RSA_E_ARG, "swin_mlp_block: bad geometry");
+  if (p->products != 1 && p->products != 3) return set_error(RSA_E_UNSUPPORTED, "swin_mlp_block: products must be 1 or 3");
+  if (p->C > 256 || (p->C & 3) || p->hidden > 512) return set_error(RSA_E_UNSUPPORTED, "swin_mlp_block: C must be a multiple of 4, at most 256; hidden at most 512");
+  if (!p->x || !p->gamma || !p->beta || !p->w1 || !p->b1 || !p->w2 || !p->b2 || !p->out) return set_error(RSA_E_ARG, "swin_mlp_block: null pointer");
+  if (!aligned16(p->x) || !aligned16(p->gamma) || !aligned16(p->beta) || !aligned16(p->w1) || !aligned16(p->b1) || !aligned16(p->w2) || !aligned16(p->b2) ||
+      !aligned16(p->out) || !aligned16(p->out_hi) || !aligned16(p->out_lo))
+    return set_error(RSA_E_ALIGN, "swin_mlp_block: pointers must be 16-byte aligned");
+  const int64_t tiles = (int64_t)p->batch * (((int64_t)p->H * p->W + SB_TOK - 1) / SB_TOK);
+  if (tiles > 0x7fffffff) return set_error(RSA_E_UNSUPPORTED, "swin_mlp_block: too many tokens");
+  if (p->products == 3)
+    hipLaunchKernelGGL(swin_mlp_block_kernel<3>, dim3((unsigned)tiles), dim3(512), 0, (hipStream_t)stream, *p);
+  else
+    hipLaunchKernelGGL(swin_mlp_block_kernel<1>, dim3((unsigned)tiles), dim3(512), 0, (hipStream_t)stream, *p);
+  const int rc = (int)hipGetLastError();
+  return rc ? set_error(rc, "swin_mlp_block: launch failed") : RSA_OK;
+}

@@ -111,6 +111,57 @@ class LayerNormParams(C.Structure):
     ]
 
 
+class SwinAttnBlockParams(C.Structure):
+    """Mirror of ``struct rsa_swin_attn_block_params``."""
+
+    _fields_ = [
+        ('batch', C.c_int32),
+        ('H', C.c_int32),
+        ('W', C.c_int32),
+        ('C', C.c_int32),
+        ('heads', C.c_int32),
+        ('window', C.c_int32),
+        ('shift', C.c_int32),
+        ('products', C.c_int32),
+        ('eps', C.c_float),
+        ('x', C.c_void_p),
+        ('gamma', C.c_void_p),
+        ('beta', C.c_void_p),
+        ('wqkv', C.c_void_p),
+        ('bqkv', C.c_void_p),
+        ('bias_frag16', C.c_void_p),
+        ('wproj', C.c_void_p),
+        ('bproj', C.c_void_p),
+        ('out', C.c_void_p),
+    ]
+
+
+class SwinMlpBlockParams(C.Structure):
+    """Mirror of ``struct rsa_swin_mlp_block_params``."""
+
+    _fields_ = [
+        ('batch', C.c_int32),
+        ('H', C.c_int32),
+        ('W', C.c_int32),
+        ('C', C.c_int32),
+        ('hidden', C.c_int32),
+        ('products', C.c_int32),
+        ('eps', C.c_float),
+        ('x', C.c_void_p),
+        ('gamma', C.c_void_p),
+        ('beta', C.c_void_p),
+        ('w1', C.c_void_p),
+        ('b1', C.c_void_p),
+        ('w2', C.c_void_p),
+        ('b2', C.c_void_p),
+        ('out', C.c_void_p),
+        ('out_hi', C.c_void_p),
+        ('out_lo', C.c_void_p),
+        ('out_plane_stride', C.c_int64),
+        ('out_batch_stride', C.c_int64),
+    ]
+
+
 class WindowAttnParams(C.Structure):
     """Mirror of ``struct rsa_window_attn_params``."""
 
@@ -316,6 +367,8 @@ EXPORTS = (
     'rsa_dysample',
     'rsa_layernorm',
     'rsa_window_attention',
+    'rsa_swin_attn_block',
+    'rsa_swin_mlp_block',
     'rsa_rect_attention',
     'rsa_channel_attn_workspace_bytes',
     'rsa_channel_attention_weights',
@@ -406,6 +459,10 @@ def load() -> C.CDLL:
     lib.rsa_layernorm.restype = C.c_int
     lib.rsa_window_attention.argtypes = [C.POINTER(WindowAttnParams), C.c_void_p]
     lib.rsa_window_attention.restype = C.c_int
+    lib.rsa_swin_attn_block.argtypes = [C.POINTER(SwinAttnBlockParams), C.c_void_p]
+    lib.rsa_swin_attn_block.restype = C.c_int
+    lib.rsa_swin_mlp_block.argtypes = [C.POINTER(SwinMlpBlockParams), C.c_void_p]
+    lib.rsa_swin_mlp_block.restype = C.c_int
     for name, struct in (('rsa_rect_attention', RectAttnParams), ('rsa_channel_attention_weights', ChannelAttnParams), ('rsa_dwconv3x3', DwConvParams),
                          ('rsa_channel_gate', ChannelGateParams), ('rsa_aim_combine', AimParams)):  # fmt: skip
         getattr(lib, name).argtypes = [C.POINTER(struct), C.c_void_p]
