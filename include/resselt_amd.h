@@ -274,7 +274,7 @@ int rsa_window_attention(const rsa_window_attn_params* p, void* stream);
  * 4*heads), w1 [hidden][C] (cin_planes = ceil(C/8)), w2 [C][hidden] (cin_planes = ceil(hidden/8)).  Biases are f32 vectors padded
  * with zeros to a multiple of 16.  bias_frag16: relative_position_bias_table[relative_position_index] in the accumulator order of
  * 16x16 tiles, [head][key tile 4][query tile 4][lane 64][4] f32: lane l, element r <-> key 16*kt + 4*(l >> 4) + r, query
- * 16*qt + (l & 15); key slots beyond window^2 carry -1e30.  Limits: C <= 256 (a multiple of 4), heads <= 8, head_dim <= 32,
+ * 16*qt + (l & 15), every value multiplied by log2(e) (the kernel's softmax runs in base 2); key slots beyond window^2 carry -1e30.  Limits: C <= 256 (a multiple of 4), heads <= 8, head_dim <= 32,
  * window <= 8, hidden <= 512; `out` may be `x` (in place). */
 typedef struct rsa_swin_attn_block_params {
   int32_t batch;

@@ -73,12 +73,13 @@ def bias_fragments(table: torch.Tensor, index: torch.Tensor, window: int) -> tor
 
 def bias_fragments16(table: torch.Tensor, index: torch.Tensor, window: int) -> torch.Tensor:
     """The same gather in the accumulator order of 16x16 tiles (csrc/swin_block.hip): [heads][kt 4][qt 4][lane 64][4] f32,
-    lane l, element r  <->  key 16*kt + 4*(l >> 4) + r,  query 16*qt + (l & 15).  Padded keys get -1e30."""
+    lane l, element r  <->  key 16*kt + 4*(l >> 4) + r,  query 16*qt + (l & 15).  Values are multiplied by log2(e): the kernel's
+    softmax runs in base 2 (one v_exp_f32 per logit).  Padded keys get -1e30."""
     n = window * window
     heads = table.shape[1]
     dense = torch.zeros((heads, 64, 64), dtype=torch.float32, device=table.device)  # [head][query][key]
     dense[:, :, n:] = -1e30
-    dense[:, :n, :n] = table.to(torch.float32)[index.reshape(-1).long()].reshape(n, n, heads).permute(2, 0, 1)
+    dense[:, :n, :n] = table.to(torch.float32)[index.reshape(-1).long()].reshape(n, n, heads).permute(2, 0, 1) * math.log2(math.e)
     lane = torch.arange(64, device=table.device)
     r = torch.arange(4, device=table.device)
     q_in = (lane & 15)[:, None].expand(64, 4)

@@ -26,106 +26,149 @@ namespace rsa {
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 constexpr int SB_TOK = 64;  // tokens per workgroup
+constexpr float LOG2E = 1.44269504088896340736f;
 
-// LayerNorm of the workgroup's tokens into the LDS plane image.  pix_of(t): pixel of token t in its image, or -1 (no such token:
-// the image gets zeros).  Planes [ceil(C/8), planes_pad) are zeroed (K padding of the multiply that follows).
-template <int PROD, typename PixOf>
-__device__ __forceinline__ void ln_to_lds(uint4* lds, int lo0, int planes_pad, const f32x4* x_img, int64_t HW, int C, const float* gamma,
-                                          const float* beta, float eps, int wave, int nwaves, int lane, PixOf pix_of) {
-  const int j = lane >> 3, tok8 = lane & 7;
+// Timing experiments only (tools/variant.sh NAME -DRSA_SB_ABL=mask swin_block): 1 no residual-stream loads in the LayerNorm, 2 no
+// GELU / exp, 4 no MFMAs in the Linear layers, 8 no operand fetches there, 16 no residual loads / stores in the epilogues, 32 every weight fetch reads K chunk 0 (no L2 streaming).  Results
+// are wrong in every one of them.
+#ifndef RSA_SB_ABL
+#define RSA_SB_ABL 0
+#endif
+// (64: the residual stream addressed token-major, [pixel][group], instead of [group][pixel])
+#define MAPIDX(g, pix) ((RSA_SB_ABL & 64) ? (int64_t)(pix) * p4 + (g) : (int64_t)(g) * HW + (pix))
+
+// LayerNorm of the workgroup's tokens into the LDS plane image, in two steps so that the loads of the NEXT tile can be in flight during
+// the last multiply of the current one.  Lane (j, tok8) = token 8*row + tok8, planes j, j+8, j+16, j+24; wave w owns row w (rows
+// w + nwaves, ... of a workgroup with fewer than 8 waves are loaded where they are used).
+struct LnRow {
+  f32x4 v[4][2];
+};
+
+__device__ __forceinline__ void ln_load(LnRow& r, const f32x4* x_img, int64_t HW, int p4, int64_t pix, int lane) {
+  const int j = lane >> 3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int g = (j + 8 * i) * 2 + h;
+      r.v[i][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (pix >= 0 && g < p4 && !(RSA_SB_ABL & 1)) r.v[i][h] = x_img[MAPIDX(g, pix)];  // C % 4 == 0: a group is whole or absent
+      if (RSA_SB_ABL & 1) r.v[i][h] = (f32x4){0.1f * (float)g, 0.3f, -0.2f * (float)lane, 1.f};
+    }
+}
+
+// statistics by lane shuffles (the 8 lanes of a token sit 8 apart), result as split planes; planes [ceil(C/8), planes_pad) and
+// tokens without a pixel (pix < 0) get zeros
+template <int PROD>
+__device__ __forceinline__ void ln_store(const LnRow& r, uint4* lds, int lo0, int planes_pad, int C, const float* gamma, const float* beta, float eps,
+                                         int t, int64_t pix, int lane) {
+  const int j = lane >> 3;
   const int p4 = (C + 3) >> 2;
   const float inv_c = 1.f / (float)C;
-  for (int row = wave; row < 8; row += nwaves) {
-    const int t = row * 8 + tok8;
-    const int64_t pix = pix_of(t);
-    f32x4 v[4][2];
-    float sum = 0.f;
+  float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int g = (j + 8 * i) * 2 + h;
-        v[i][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (pix >= 0 && g < p4) v[i][h] = x_img[(int64_t)g * HW + pix];  // C % 4 == 0: a group is whole or absent
-        sum += (v[i][h][0] + v[i][h][1]) + (v[i][h][2] + v[i][h][3]);
-      }
-    sum += __shfl_xor(sum, 8);
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    const float mean = sum * inv_c;
-    float var = 0.f;
+    for (int h = 0; h < 2; ++h) sum += (r.v[i][h][0] + r.v[i][h][1]) + (r.v[i][h][2] + r.v[i][h][3]);
+  sum += __shfl_xor(sum, 8);
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  const float mean = sum * inv_c;
+  float var = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int g = (j + 8 * i) * 2 + h;
-        if (g < p4) {
+    for (int h = 0; h < 2; ++h) {
+      const int g = (j + 8 * i) * 2 + h;
+      if (g < p4) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float d = v[i][h][r] - mean;
-            var += d * d;
-          }
+        for (int e = 0; e < 4; ++e) {
+          const float d = r.v[i][h][e] - mean;
+          var += d * d;
         }
       }
-    var += __shfl_xor(var, 8);
-    var += __shfl_xor(var, 16);
-    var += __shfl_xor(var, 32);
-    const float rstd = rsqrtf(var * inv_c + eps);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int pl = j + 8 * i;
-      if (pl >= planes_pad) continue;
-      uint32_t h[4], l[4];
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const int g = pl * 2 + hh;
-        f32x4 y = {0.f, 0.f, 0.f, 0.f};
-        if (pix >= 0 && g < p4) {
-          const f32x4 ga = ((const f32x4*)gamma)[g], be = ((const f32x4*)beta)[g];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) y[r] = (v[i][hh][r] - mean) * rstd * ga[r] + be[r];
-        }
-        split2(y[0], y[1], h[2 * hh], l[2 * hh]);
-        split2(y[2], y[3], h[2 * hh + 1], l[2 * hh + 1]);
-      }
-      lds[pl * SB_TOK + t] = make_uint4(h[0], h[1], h[2], h[3]);
-      if (PROD == 3) lds[lo0 + pl * SB_TOK + t] = make_uint4(l[0], l[1], l[2], l[3]);
     }
+  var += __shfl_xor(var, 8);
+  var += __shfl_xor(var, 16);
+  var += __shfl_xor(var, 32);
+  const float rstd = rsqrtf(var * inv_c + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pl = j + 8 * i;
+    if (pl >= planes_pad) continue;
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int g = pl * 2 + hh;
+      f32x4 y = {0.f, 0.f, 0.f, 0.f};
+      if (pix >= 0 && g < p4) {
+        const f32x4 ga = ((const f32x4*)gamma)[g], be = ((const f32x4*)beta)[g];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (r.v[i][hh][e] - mean) * rstd * ga[e] + be[e];
+      }
+      split2(y[0], y[1], h[2 * hh], l[2 * hh]);
+      split2(y[2], y[3], h[2 * hh + 1], l[2 * hh + 1]);
+    }
+    lds[pl * SB_TOK + t] = make_uint4(h[0], h[1], h[2], h[3]);
+    if (PROD == 3) lds[lo0 + pl * SB_TOK + t] = make_uint4(l[0], l[1], l[2], l[3]);
   }
+}
+
+// The weight fragments of K chunk 0 of a multiply, fetched by the caller long before the multiply starts (ahead of a barrier, of the
+// LayerNorm arithmetic, of the softmax): the first L2 round trip of every Linear layer would otherwise be exposed in all waves at once.
+template <int PROD, int CTW>
+struct W0 {
+  bf16x8 w[CTW][PROD == 3 ? 2 : 1];
+};
+
+template <int PROD, int CTW>
+__device__ __forceinline__ void w0_load(W0<PROD, CTW>& f, const __amdgpu_buffer_rsrc_t rw, const uint32_t (&woff)[CTW]) {
+  constexpr int NHL = PROD == 3 ? 2 : 1;
+#pragma unroll
+  for (int c = 0; c < CTW; ++c)
+#pragma unroll
+    for (int hl = 0; hl < NHL; ++hl) f.w[c][hl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, woff[c], (uint32_t)hl * 1024u, 0));
 }
 
 // acc[c][pt] += W[cout tile c][K] . X[K][token tile pt]  over nk chunks of 32 channels.  X: LDS plane image (hi at 0, lo at lo0);
 // W: packed blob (layout 0, ksize 1: [chunk][cout tile][hi|lo][lane][8]) behind the buffer resource rw, woff[c] = byte offset of
 // this lane's fragment of cout tile c inside a chunk, or 0xFFFFFFFF (a tile beyond the layer: the range check of the buffer load
 // looks at the vector offset alone and returns zeros).  SWAP: tokens on the MFMA rows (D[token][channel]) instead of the columns.
-template <int PROD, int CTW, int NPT, bool SWAP>
+// XDB false: the token fragments are single-buffered (32 registers less; their LDS latency is then exposed once per chunk).
+template <int PROD, int CTW, int NPT, bool SWAP, bool XDB = true>
 __device__ __forceinline__ void gemm_tile(f32x4 (&acc)[CTW][NPT], const uint4* lds, int lo0, int nk, const __amdgpu_buffer_rsrc_t rw,
-                                          const uint32_t (&woff)[CTW], uint32_t wstep, int li, int lg) {
+                                          const uint32_t (&woff)[CTW], uint32_t wstep, const W0<PROD, CTW>& w0, int li, int lg) {
   constexpr int NHL = PROD == 3 ? 2 : 1;
-  bf16x8 wn[CTW][NHL];
-  auto load_w = [&](int kc) {
+  const int bu = lg * SB_TOK + li;
+  bf16x8 w[2][CTW][NHL], bh[XDB ? 2 : 1][NPT], bl[XDB ? 2 : 1][NPT];  // [buffer]: chunk kc lives in buffer kc & 1
+  auto fetch_w = [&](int kc, int b) {
+    if (RSA_SB_ABL & 8) return;
 #pragma unroll
     for (int c = 0; c < CTW; ++c)
 #pragma unroll
       for (int hl = 0; hl < NHL; ++hl)
-        wn[c][hl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, woff[c], (uint32_t)kc * wstep + (uint32_t)hl * 1024u, 0));
+        w[b][c][hl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, woff[c], ((RSA_SB_ABL & 32) ? 0u : (uint32_t)kc * wstep) + (uint32_t)hl * 1024u, 0));
   };
-  load_w(0);
-  const int bu = lg * SB_TOK + li;
-#pragma unroll 1
-  for (int kc = 0; kc < nk; ++kc) {
-    bf16x8 wc[CTW][NHL];
-#pragma unroll
-    for (int c = 0; c < CTW; ++c)
-#pragma unroll
-      for (int hl = 0; hl < NHL; ++hl) wc[c][hl] = wn[c][hl];
-    load_w(kc + 1 < nk ? kc + 1 : kc);  // one chunk ahead (the last iteration re-reads its own chunk: no branch around the loads)
-    bf16x8 bh[NPT], bl[NPT];
+  auto fetch_x = [&](int kc, int b_) {
+    const int b = XDB ? b_ : 0;
+    if (RSA_SB_ABL & 8) return;
 #pragma unroll
     for (int pt = 0; pt < NPT; ++pt) {
       const int u = kc * 4 * SB_TOK + bu + 16 * pt;
-      bh[pt] = __builtin_bit_cast(bf16x8, lds[u]);
-      if (PROD == 3) bl[pt] = __builtin_bit_cast(bf16x8, lds[lo0 + u]);
+      bh[b][pt] = __builtin_bit_cast(bf16x8, lds[u]);
+      if (PROD == 3) bl[b][pt] = __builtin_bit_cast(bf16x8, lds[lo0 + u]);
+    }
+  };
+  auto multiply = [&](int b) {
+    const int xb = XDB ? b : 0;
+    if (RSA_SB_ABL & 4) {  // keep the fetched operands alive
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt) asm volatile("" ::"v"(bh[xb][pt]), "v"(bl[xb][pt]));
+#pragma unroll
+      for (int c = 0; c < CTW; ++c)
+#pragma unroll
+        for (int hl = 0; hl < NHL; ++hl) asm volatile("" ::"v"(w[b][c][hl]));
+      return;
     }
 #pragma unroll
     for (int pt = 0; pt < NPT; ++pt)
@@ -133,15 +176,54 @@ __device__ __forceinline__ void gemm_tile(f32x4 (&acc)[CTW][NPT], const uint4* l
       for (int c = 0; c < CTW; ++c) {
         // products in increasing magnitude: w_lo*x_hi, w_hi*x_lo, w_hi*x_hi
         if (PROD == 3) {
-          acc[c][pt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[pt], wc[c][NHL - 1], acc[c][pt], 0, 0, 0)
-                            : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[c][NHL - 1], bh[pt], acc[c][pt], 0, 0, 0);
-          acc[c][pt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[pt], wc[c][0], acc[c][pt], 0, 0, 0)
-                            : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[c][0], bl[pt], acc[c][pt], 0, 0, 0);
+          acc[c][pt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[xb][pt], w[b][c][NHL - 1], acc[c][pt], 0, 0, 0)
+                            : __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[b][c][NHL - 1], bh[xb][pt], acc[c][pt], 0, 0, 0);
+          acc[c][pt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[xb][pt], w[b][c][0], acc[c][pt], 0, 0, 0)
+                            : __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[b][c][0], bl[xb][pt], acc[c][pt], 0, 0, 0);
         }
-        acc[c][pt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[pt], wc[c][0], acc[c][pt], 0, 0, 0)
-                          : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[c][0], bh[pt], acc[c][pt], 0, 0, 0);
+        acc[c][pt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[xb][pt], w[b][c][0], acc[c][pt], 0, 0, 0)
+                          : __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[b][c][0], bh[xb][pt], acc[c][pt], 0, 0, 0);
       }
+  };
+  if (RSA_SB_ABL & 8) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt) bh[XDB ? b : 0][pt] = bl[XDB ? b : 0][pt] = __builtin_bit_cast(bf16x8, make_uint4(0x3f803e12u + li, 0xbe993f01u, 0x3dcc3e4cu + lg, 0x3f003f11u));
+#pragma unroll
+      for (int c = 0; c < CTW; ++c)
+#pragma unroll
+        for (int hl = 0; hl < NHL; ++hl) w[b][c][hl] = bh[b][0];
+    }
   }
+  // Both operands one chunk ahead of the multiply, two chunks per iteration so that the buffers are named, not copied.  No fetch
+  // sits under a branch (after a conditional fetch the compiler no longer knows how many loads are outstanding and waits for ALL of
+  // them, the chunk just requested included, before the first MFMA), and scheduling barriers keep the machine scheduler from
+  // sinking the fetches to their uses.  An odd chunk count leaves its last chunk in buffer 0 for the tail multiply; an even one
+  // fetches its last chunk a second time instead of nothing.
+#pragma unroll
+  for (int c = 0; c < CTW; ++c)
+#pragma unroll
+    for (int hl = 0; hl < NHL; ++hl) w[0][c][hl] = w0.w[c][hl];
+  fetch_x(0, 0);
+  int kc = 0;
+#pragma unroll 1
+  for (; kc + 1 < nk; kc += 2) {
+    fetch_w(kc + 1, 1);
+    if (XDB) fetch_x(kc + 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!XDB) fetch_x(kc + 1, 0);
+    const int k2 = kc + 2 < nk ? kc + 2 : kc + 1;
+    fetch_w(k2, 0);
+    if (XDB) fetch_x(k2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!XDB) fetch_x(k2, 0);
+  }
+  if (kc < nk) multiply(0);
 }
 
 // eight f32 values -> the bf16 hi fragment and (PROD 3) the residual fragment
@@ -153,6 +235,29 @@ __device__ __forceinline__ void frag_of(const f32x4 a, const f32x4 b, bf16x8& hi
   split2(b[2], b[3], h[3], l[3]);
   hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
   lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+}
+
+// GELU(x) = x/2 * (1 + erf(x / sqrt 2)) with erf as the rational x * P(x^2) / Q(x^2) on [-4, 4] (the f32 approximation used by the
+// tensor libraries; |error| of erf <= 4.5e-7, of GELU <= 2.5e-7 * max(1, |x|)): 17 instructions and no branch, against the two-branch
+// erff of the device library (the MLP's hidden map costs 64 GELUs per lane and tile, beside 96 MFMAs).
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float t = __builtin_amdgcn_fmed3f(x * 0.70710678118654752440f, -4.f, 4.f);
+  const float t2 = t * t;
+  float pn = -2.72614225801306e-10f;
+  pn = fmaf(pn, t2, 2.77068142495902e-08f);
+  pn = fmaf(pn, t2, -2.10102402082508e-06f);
+  pn = fmaf(pn, t2, -5.69250639462346e-05f);
+  pn = fmaf(pn, t2, -7.34990630326855e-04f);
+  pn = fmaf(pn, t2, -2.95459980854025e-03f);
+  pn = fmaf(pn, t2, -1.60960333262415e-02f);
+  float qd = -1.45660718464996e-05f;
+  qd = fmaf(qd, t2, -2.13374055278905e-04f);
+  qd = fmaf(qd, t2, -1.68282697438203e-03f);
+  qd = fmaf(qd, t2, -7.37332916720468e-03f);
+  qd = fmaf(qd, t2, -1.42647390514189e-02f);
+  const float e = pn * t * __builtin_amdgcn_rcpf(qd);
+  const float hx = 0.5f * x;
+  return fmaf(hx, e, hx);
 }
 
 template <int PROD>
@@ -181,22 +286,41 @@ __device__ __forceinline__ void pair_units(const f32x4 a, const f32x4 b, uint4& 
   ul = make_uint4(l0.x, l1.x, l0.y, l1.y);
 }
 
+// Every workgroup of a launch takes the same time, so without help the whole chip moves in step: all CUs load, then all multiply,
+// then all store, and the memory phases run at the full HBM rate with the matrix pipes idle.  The workgroups of the first generation
+// (the ones resident when the launch starts) therefore start spread over about one tile time; every later workgroup starts when an
+// earlier one ends and inherits its phase.
+#ifndef RSA_SB_STAGGER
+#define RSA_SB_STAGGER 1
+#endif
+__device__ __forceinline__ void stagger_first_generation(int first_gen, int steps_total) {
+  if (!RSA_SB_STAGGER || (int)blockIdx.x >= first_gen) return;
+  const int steps = (int)(((blockIdx.x * 0x9E3779B1u) >> 16) % (unsigned)steps_total);  // scattered over the CUs
+  for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(32);  // ~2048 cycles, ~1 us
+}
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const void* w, int64_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (uint32_t)bytes, 0x00020000);
 }
 
 // ------------------------------------------------------------------------------------------------ attention half
-// One workgroup = one (shifted) window; `heads` waves, wave = head.
+// One workgroup = one (shifted) window.  ceil(heads / 2) waves, each running two heads one after the other: a workgroup of four waves
+// (one per SIMD) with 64 KB of LDS, so that TWO windows are resident on a CU and the phases of one that issue no MFMA (LayerNorm loads
+// and arithmetic, softmax, the epilogue's loads and stores, barriers -- 44 % of a window's time when it had the CU to itself) run
+// beside the multiplies of the other.
 template <int PROD>
-__global__ __launch_bounds__(512) void swin_attn_block_kernel(const rsa_swin_attn_block_params p) {
+__global__ __launch_bounds__(256, 2) void swin_attn_block_kernel(const rsa_swin_attn_block_params p) {
   constexpr int XPL = 32;  // planes of the LDS image (256 channels)
   constexpr int LO0 = XPL * SB_TOK;
   constexpr int NHL = PROD == 3 ? 2 : 1;
+  constexpr int HPW = 2;  // heads per wave
   __shared__ uint4 s_x[2 * XPL * SB_TOK];  // 64 KB: LayerNorm image, later the attention output image
 
+  stagger_first_generation(512, 64 * RSA_SB_STAGGER);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int heads = p.heads;
+  const int nw = (heads + HPW - 1) / HPW;  // waves of the workgroup
   const int li = lane & 15, lg = lane >> 4;
   const int w = p.window, ntok = w * w;
   const int nwx = p.W / w, nwy = p.H / w;
@@ -206,166 +330,223 @@ __global__ __launch_bounds__(512) void swin_attn_block_kernel(const rsa_swin_att
   const int p4 = (p.C + 3) >> 2;
   const int planes = (p.C + 7) >> 3;
   const int nk = (planes + 3) >> 2;
+  const int ct_qkv = 3 * heads * 2;
+  const int ct_c = (p.C + 15) >> 4;
+  const __amdgpu_buffer_rsrc_t rq = weight_rsrc(p.wqkv, (int64_t)nk * ct_qkv * NHL * 1024);
+  const __amdgpu_buffer_rsrc_t rp = weight_rsrc(p.wproj, (int64_t)heads * ct_c * NHL * 1024);
+  const uint32_t qstep = (uint32_t)ct_qkv * NHL * 1024u;
+  const f32x4* bqkv4 = (const f32x4*)p.bqkv;
+  const uint32_t wdiv = 65536u / (uint32_t)w + 1u;  // t / w == (t * wdiv) >> 16 for t < 64, w <= 8
 
   // pixel of window token t after the cyclic shift (torch.roll(-s), partition; the result is rolled back, so a token's output
   // lands on the pixel it was read from)
   auto token_pix = [&](int t) -> int64_t {
     if (t >= ntok) return -1;
-    const int ty = t / w, tx = t - ty * w;
+    const int ty = (int)(((uint32_t)t * wdiv) >> 16), tx = t - ty * w;
     int py = wy * w + ty + p.shift, px = wx * w + tx + p.shift;
     if (py >= p.H) py -= p.H;
     if (px >= p.W) px -= p.W;
     return (int64_t)py * p.W + px;
   };
   const f32x4* x_img = (const f32x4*)p.x + (int64_t)n * p4 * HW;
-  ln_to_lds<PROD>(s_x, LO0, 4 * nk, x_img, HW, p.C, p.gamma, p.beta, p.eps, wave, heads, lane, token_pix);
+
+  // ---- LayerNorm -> LDS image (the first K chunk of the first head's q / k weights is on its way meanwhile) ----
+  uint32_t woff_qk[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) woff_qk[c] = (uint32_t)(((((c >> 1) * heads + wave) * 2 + (c & 1)) * NHL * 64 + lane) * 16);
+  W0<PROD, 4> w0qk;
+  w0_load<PROD, 4>(w0qk, rq, woff_qk);
+  for (int r = wave; r < 8; r += nw) {
+    const int t = r * 8 + (lane & 7);
+    const int64_t pix = token_pix(t);
+    LnRow row;
+    ln_load(row, x_img, HW, p4, pix, lane);
+    ln_store<PROD>(row, s_x, LO0, 4 * nk, p.C, p.gamma, p.beta, p.eps, t, pix, lane);
+  }
   __syncthreads();
 
-  const int head = wave;
-  const int ct_qkv = 3 * heads * 2;
-  const __amdgpu_buffer_rsrc_t rq = weight_rsrc(p.wqkv, (int64_t)nk * ct_qkv * NHL * 1024);
-  const uint32_t qstep = (uint32_t)ct_qkv * NHL * 1024u;
-  const f32x4* bqkv4 = (const f32x4*)p.bqkv;
+  // shift mask: img_mask region id (arch.py:268-293) of this lane's query column and key rows on the SHIFTED grid, 4 bits each
+  const bool masked = p.shift > 0 && (wy == nwy - 1 || wx == nwx - 1);
+  uint32_t qreg = 0, kreg[4] = {0, 0, 0, 0};
+  if (masked) {
+    auto region = [&](int t) -> uint32_t {
+      const int tt = t < ntok ? t : 0;
+      const int ty = (int)(((uint32_t)tt * wdiv) >> 16), tx = tt - ty * w;
+      const int gy = wy * w + ty, gx = wx * w + tx;
+      const int ry = gy < p.H - w ? 0 : (gy < p.H - p.shift ? 1 : 2);
+      const int rx = gx < p.W - w ? 0 : (gx < p.W - p.shift ? 1 : 2);
+      return (uint32_t)(ry * 3 + rx);
+    };
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      qreg |= region(16 * t4 + li) << (4 * t4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) kreg[t4] |= region(16 * t4 + 4 * lg + r) << (4 * r);
+    }
+  }
 
-  // ---- q and k of this head: D[channel 16*dt + 4*lg + r][token 16*tt + li] ----
-  bf16x8 qh[4], ql[4], kh[4], kl[4];
+  uint4 ouh[HPW][4], oul[HPW][4];  // attention output of this wave's heads as plane units, until every wave is done with the image
+#pragma unroll
+  for (int hi = 0; hi < HPW; ++hi) {
+    const int head = wave + hi * nw;
+    if (head >= heads) break;  // wave-uniform
+    uint32_t woff_v[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) woff_v[c] = (uint32_t)((((2 * heads + head) * 2 + c) * NHL * 64 + lane) * 16);
+    if (hi > 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) woff_qk[c] = (uint32_t)(((((c >> 1) * heads + head) * 2 + (c & 1)) * NHL * 64 + lane) * 16);
+      w0_load<PROD, 4>(w0qk, rq, woff_qk);
+    }
+    // ---- q and k of this head: D[channel 16*dt + 4*lg + r][token 16*tt + li] ----
+    bf16x8 qh[4], ql[4], kh[4], kl[4];
+    W0<PROD, 2> w0v;
+    {
+      f32x4 a[4][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) a[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // (the second head runs with the first one's output held in 32 registers: single-buffered token fragments there)
+      if (hi == 0)
+        gemm_tile<PROD, 4, 4, false, true>(a, s_x, LO0, nk, rq, woff_qk, qstep, w0qk, li, lg);
+      else
+        gemm_tile<PROD, 4, 4, false, false>(a, s_x, LO0, nk, rq, woff_qk, qstep, w0qk, li, lg);
+      w0_load<PROD, 2>(w0v, rq, woff_v);
+      f32x4 b[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) b[c] = bqkv4[(((c >> 1) * heads + head) * 2 + (c & 1)) * 4 + lg];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        frag_of(a[0][tt] + b[0], a[1][tt] + b[1], qh[tt], ql[tt]);
+        frag_of(a[2][tt] + b[2], a[3][tt] + b[3], kh[tt], kl[tt]);
+      }
+    }
+    // ---- v of this head with the operands swapped: D[token 16*tt + 4*lg + r][channel 16*dt + li] ----
+    bf16x8 vh[2][2], vl[2][2];  // [dt][key tile pair]
+    {
+      f32x4 a[2][4];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) a[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (hi == 0)
+        gemm_tile<PROD, 2, 4, true, true>(a, s_x, LO0, nk, rq, woff_v, qstep, w0v, li, lg);
+      else
+        gemm_tile<PROD, 2, 4, true, false>(a, s_x, LO0, nk, rq, woff_v, qstep, w0v, li, lg);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const float bv = p.bqkv[((2 * heads + head) * 2 + dt) * 16 + li];
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp) frag_of(a[dt][2 * kp] + bv, a[dt][2 * kp + 1] + bv, vh[dt][kp], vl[dt][kp]);
+      }
+    }
+    // ---- attention of this head, in registers ----
+    f32x4 o[2][4];  // O^T: D[channel 16*dt + 4*lg + r][query 16*qt + li]
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      f32x4 s[4];  // S^T: D[key 16*kt + 4*lg + r][query 16*qt + li]
+      const uint32_t rq_ = (qreg >> (4 * qt)) & 15u;
+      float m = -3.0e38f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        s[kt] = mfma3<PROD>(kh[kt], kl[kt], qh[qt], ql[qt], (f32x4){0.f, 0.f, 0.f, 0.f});
+        const f32x4 bf = ((const f32x4*)p.bias_frag16)[(((int64_t)head * 4 + kt) * 4 + qt) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = fmaf(s[kt][r], LOG2E, bf[r]);  // base-2 logits: the bias fragments are stored multiplied by log2(e)
+          if (masked && ((kreg[kt] >> (4 * r)) & 15u) != rq_) v += -100.f * LOG2E;
+          s[kt][r] = v;
+          m = fmaxf(m, v);
+        }
+      }
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      float l = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = (RSA_SB_ABL & 2) ? s[kt][r] - m : __builtin_amdgcn_exp2f(s[kt][r] - m);  // v_exp_f32: arguments <= 0, underflow to 0 is the wanted result
+          s[kt][r] = e;
+          l += e;
+        }
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      const float inv_l = 1.f / l;
+      bf16x8 ph[2], pl[2];
+#pragma unroll
+      for (int kp = 0; kp < 2; ++kp) frag_of(s[2 * kp], s[2 * kp + 1], ph[kp], pl[kp]);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp) acc = mfma3<PROD>(vh[dt][kp], vl[dt][kp], ph[kp], pl[kp], acc);
+        o[dt][qt] = acc * inv_l;
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) pair_units(o[dt][2 * k], o[dt][2 * k + 1], ouh[hi][dt * 2 + k], oul[hi][dt * 2 + k]);
+  }
+  uint32_t woff_p[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) woff_p[c] = (4 * wave + c < ct_c) ? (uint32_t)(((4 * wave + c) * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
+  W0<PROD, 4> w0p;
+  w0_load<PROD, 4>(w0p, rp, woff_p);
+  __syncthreads();  // every wave has read the LayerNorm image for the last time: the attention output may overwrite it
+  // ---- attention output -> LDS planes [head*4 + dt*2 + (lg >> 1)][token] ----
+#pragma unroll
+  for (int hi = 0; hi < HPW; ++hi) {
+    const int head = wave + hi * nw;
+    if (head >= heads) break;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int u = (head * 4 + dt * 2 + (lg >> 1)) * SB_TOK + 16 * (2 * k + (lg & 1)) + li;
+        s_x[u] = ouh[hi][dt * 2 + k];
+        if (PROD == 3) s_x[LO0 + u] = oul[hi][dt * 2 + k];
+      }
+  }
+  __syncthreads();
+
+  // ---- proj + bias + shortcut -> residual stream: wave owns cout tiles 4*wave .. +3 ----
   {
     f32x4 a[4][4];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int pt = 0; pt < 4; ++pt) a[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    uint32_t woff[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) woff[c] = (uint32_t)(((((c >> 1) * heads + head) * 2 + (c & 1)) * NHL * 64 + lane) * 16);
-    gemm_tile<PROD, 4, 4, false>(a, s_x, LO0, nk, rq, woff, qstep, li, lg);
-    f32x4 b[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) b[c] = bqkv4[(((c >> 1) * heads + head) * 2 + (c & 1)) * 4 + lg];
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      frag_of(a[0][tt] + b[0], a[1][tt] + b[1], qh[tt], ql[tt]);
-      frag_of(a[2][tt] + b[2], a[3][tt] + b[3], kh[tt], kl[tt]);
-    }
-  }
-  // ---- v of this head with the operands swapped: D[token 16*tt + 4*lg + r][channel 16*dt + li] ----
-  bf16x8 vh[2][2], vl[2][2];  // [dt][key tile pair]
-  {
-    f32x4 a[2][4];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int pt = 0; pt < 4; ++pt) a[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    uint32_t woff[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) woff[c] = (uint32_t)((((2 * heads + head) * 2 + c) * NHL * 64 + lane) * 16);
-    gemm_tile<PROD, 2, 4, true>(a, s_x, LO0, nk, rq, woff, qstep, li, lg);
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-      const float bv = p.bqkv[((2 * heads + head) * 2 + dt) * 16 + li];
-#pragma unroll
-      for (int kp = 0; kp < 2; ++kp) frag_of(a[dt][2 * kp] + bv, a[dt][2 * kp + 1] + bv, vh[dt][kp], vl[dt][kp]);
-    }
-  }
-  __syncthreads();  // every wave has read the LayerNorm image for the last time: the attention output may overwrite it
-
-  // ---- attention of this head, in registers ----
-  const bool masked = p.shift > 0 && (wy == nwy - 1 || wx == nwx - 1);
-  auto region = [&](int t) -> int {  // img_mask region id of a window token on the SHIFTED grid (arch.py:268-293)
-    const int tt = t < ntok ? t : 0;
-    const int ty = tt / w, tx = tt - ty * w;
-    const int gy = wy * w + ty, gx = wx * w + tx;
-    const int ry = gy < p.H - w ? 0 : (gy < p.H - p.shift ? 1 : 2);
-    const int rx = gx < p.W - w ? 0 : (gx < p.W - p.shift ? 1 : 2);
-    return ry * 3 + rx;
-  };
-  f32x4 o[2][4];  // O^T: D[channel 16*dt + 4*lg + r][query 16*qt + li]
-#pragma unroll
-  for (int qt = 0; qt < 4; ++qt) {
-    f32x4 s[4];  // S^T: D[key 16*kt + 4*lg + r][query 16*qt + li]
-    const int rq_ = masked ? region(16 * qt + li) : 0;
-    float m = -3.0e38f;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      s[kt] = mfma3<PROD>(kh[kt], kl[kt], qh[qt], ql[qt], (f32x4){0.f, 0.f, 0.f, 0.f});
-      const f32x4 bf = ((const f32x4*)p.bias_frag16)[(((int64_t)head * 4 + kt) * 4 + qt) * 64 + lane];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = s[kt][r] + bf[r];
-        if (masked && region(16 * kt + 4 * lg + r) != rq_) v += -100.f;
-        s[kt][r] = v;
-        m = fmaxf(m, v);
-      }
-    }
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
-    float l = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = expf(s[kt][r] - m);
-        s[kt][r] = e;
-        l += e;
-      }
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
-    const float inv_l = 1.f / l;
-    bf16x8 ph[2], pl[2];
-#pragma unroll
-    for (int kp = 0; kp < 2; ++kp) frag_of(s[2 * kp], s[2 * kp + 1], ph[kp], pl[kp]);
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kp = 0; kp < 2; ++kp) acc = mfma3<PROD>(vh[dt][kp], vl[dt][kp], ph[kp], pl[kp], acc);
-      o[dt][qt] = acc * inv_l;
-    }
-  }
-  // ---- attention output -> LDS planes [head*4 + dt*2 + (lg >> 1)][token] ----
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      uint4 uh, ul;
-      pair_units(o[dt][2 * k], o[dt][2 * k + 1], uh, ul);
-      const int u = (head * 4 + dt * 2 + (lg >> 1)) * SB_TOK + 16 * (2 * k + (lg & 1)) + li;
-      s_x[u] = uh;
-      if (PROD == 3) s_x[LO0 + u] = ul;
-    }
-  __syncthreads();
-
-  // ---- proj + bias + shortcut -> residual stream ----
-  {
-    const int ct_c = (p.C + 15) >> 4;
-    const __amdgpu_buffer_rsrc_t rp = weight_rsrc(p.wproj, (int64_t)heads * ct_c * NHL * 1024);
-    f32x4 a[2][4];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int pt = 0; pt < 4; ++pt) a[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    uint32_t woff[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) woff[c] = (2 * wave + c < ct_c) ? (uint32_t)(((2 * wave + c) * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
-    gemm_tile<PROD, 2, 4, false>(a, s_x, LO0, heads, rp, woff, (uint32_t)ct_c * NHL * 1024u, li, lg);
+    gemm_tile<PROD, 4, 4, false>(a, s_x, LO0, heads, rp, woff_p, (uint32_t)ct_c * NHL * 1024u, w0p, li, lg);
     f32x4* o_img = (f32x4*)p.out + (int64_t)n * p4 * HW;
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
       const int64_t pix = token_pix(16 * pt + li);
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int g = (2 * wave + c) * 4 + lg;
+      for (int c = 0; c < 4; ++c) {
+        const int g = (4 * wave + c) * 4 + lg;
+        if (RSA_SB_ABL & 16) {
+          asm volatile("" ::"v"(a[c][pt]));
+          continue;
+        }
         if (pix < 0 || g >= p4) continue;
         const f32x4 b = ((const f32x4*)p.bproj)[g];
-        const f32x4 r = x_img[(int64_t)g * HW + pix];
-        o_img[(int64_t)g * HW + pix] = a[c][pt] + b + r;
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (!(RSA_SB_ABL & 256)) r = x_img[MAPIDX(g, pix)];
+        if (RSA_SB_ABL & 128)
+          asm volatile("" ::"v"(a[c][pt] + b + r));
+        else
+          o_img[MAPIDX(g, pix)] = a[c][pt] + b + r;
       }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ MLP half
-// One workgroup (8 waves) = 64 consecutive tokens of one image.
+// One workgroup (8 waves) = 64 consecutive tokens of one image.  (The hidden image takes 120 KB of LDS at 480 channels: one
+// workgroup per CU.)
 template <int PROD>
 __global__ __launch_bounds__(512) void swin_mlp_block_kernel(const rsa_swin_mlp_block_params p) {
   constexpr int HPL = 64;  // planes of the LDS image (512 hidden channels)
@@ -373,6 +554,7 @@ __global__ __launch_bounds__(512) void swin_mlp_block_kernel(const rsa_swin_mlp_
   constexpr int NHL = PROD == 3 ? 2 : 1;
   __shared__ uint4 s_h[2 * HPL * SB_TOK];  // 128 KB: LayerNorm image (planes 0..31), then the hidden map
 
+  stagger_first_generation(256, 28 * RSA_SB_STAGGER);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lg = lane >> 4;
@@ -386,24 +568,50 @@ __global__ __launch_bounds__(512) void swin_mlp_block_kernel(const rsa_swin_mlp_
   const int hplanes = (p.hidden + 7) >> 3;
   const int nk2 = (hplanes + 3) >> 2;
   const int ct_h = (p.hidden + 15) >> 4, ct_c = (p.C + 15) >> 4;
+  const __amdgpu_buffer_rsrc_t r1 = weight_rsrc(p.w1, (int64_t)nk1 * ct_h * NHL * 1024);
+  const __amdgpu_buffer_rsrc_t r2 = weight_rsrc(p.w2, (int64_t)nk2 * ct_c * NHL * 1024);
+  uint32_t woff1[4], woff2[2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) woff1[c] = (4 * wave + c < ct_h) ? (uint32_t)(((4 * wave + c) * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) woff2[c] = (2 * wave + c < ct_c) ? (uint32_t)(((2 * wave + c) * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
 
   auto token_pix = [&](int t) -> int64_t { return t0 + t < HW ? t0 + t : -1; };
   const f32x4* x_img = (const f32x4*)p.x + (int64_t)n * p4 * HW;
-  ln_to_lds<PROD>(s_h, LO0, 4 * nk1, x_img, HW, p.C, p.gamma, p.beta, p.eps, wave, 8, lane, token_pix);
+
+  // ---- LayerNorm -> LDS image (the first K chunk of the fc1 weights is on its way meanwhile).  The shortcut values of the epilogue
+  //      are requested right behind the LayerNorm row: the same lines, still in L2, and their latency is over long before the
+  //      epilogue (asked for there, every wave waited for them at the end of the tile with nothing left to overlap). ----
+  W0<PROD, 4> w01;
+  w0_load<PROD, 4>(w01, r1, woff1);
+  f32x4 res[2][4];
+  {
+    const int t = wave * 8 + (lane & 7);
+    LnRow row;
+    ln_load(row, x_img, HW, p4, token_pix(t), lane);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) {
+        const int g = (2 * wave + c) * 4 + lg;
+        const int64_t pix = token_pix(16 * pt + li);
+        res[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (pix >= 0 && g < p4 && !(RSA_SB_ABL & (16 | 256))) res[c][pt] = x_img[MAPIDX(g, pix)];
+      }
+    ln_store<PROD>(row, s_h, LO0, 4 * nk1, p.C, p.gamma, p.beta, p.eps, t, token_pix(t), lane);
+  }
   __syncthreads();
 
   // ---- fc1 + GELU: wave owns hidden cout tiles 4*wave .. +3 ----
   f32x4 a1[4][4];
+  W0<PROD, 2> w02;
   {
-    const __amdgpu_buffer_rsrc_t r1 = weight_rsrc(p.w1, (int64_t)nk1 * ct_h * NHL * 1024);
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int pt = 0; pt < 4; ++pt) a1[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    uint32_t woff[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) woff[c] = (4 * wave + c < ct_h) ? (uint32_t)(((4 * wave + c) * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
-    gemm_tile<PROD, 4, 4, false>(a1, s_h, LO0, nk1, r1, woff, (uint32_t)ct_h * NHL * 1024u, li, lg);
+    gemm_tile<PROD, 4, 4, false>(a1, s_h, LO0, nk1, r1, woff1, (uint32_t)ct_h * NHL * 1024u, w01, li, lg);
+    w0_load<PROD, 2>(w02, r2, woff2);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int ct = 4 * wave + c;
@@ -412,7 +620,8 @@ __global__ __launch_bounds__(512) void swin_mlp_block_kernel(const rsa_swin_mlp_
 #pragma unroll
       for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a1[c][pt][r] = act_apply<AC_GELU>(a1[c][pt][r] + b[r], RSA_ACT_GELU, 0.f);  // tiles beyond the layer: GELU(0) = 0
+        for (int r = 0; r < 4; ++r)
+          a1[c][pt][r] = (RSA_SB_ABL & 2) ? a1[c][pt][r] + b[r] : gelu_fast(a1[c][pt][r] + b[r]);  // tiles beyond the layer: GELU(0) = 0
     }
   }
   __syncthreads();  // every wave has read the LayerNorm image for the last time
@@ -433,16 +642,12 @@ __global__ __launch_bounds__(512) void swin_mlp_block_kernel(const rsa_swin_mlp_
 
   // ---- fc2 + bias + shortcut: wave owns cout tiles 2*wave, 2*wave + 1 ----
   {
-    const __amdgpu_buffer_rsrc_t r2 = weight_rsrc(p.w2, (int64_t)nk2 * ct_c * NHL * 1024);
     f32x4 a[2][4];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int pt = 0; pt < 4; ++pt) a[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    uint32_t woff[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) woff[c] = (2 * wave + c < ct_c) ? (uint32_t)(((2 * wave + c) * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
-    gemm_tile<PROD, 2, 4, false>(a, s_h, LO0, nk2, r2, woff, (uint32_t)ct_c * NHL * 1024u, li, lg);
+    gemm_tile<PROD, 2, 4, false>(a, s_h, LO0, nk2, r2, woff2, (uint32_t)ct_c * NHL * 1024u, w02, li, lg);
     f32x4* o_img = (f32x4*)p.out + (int64_t)n * p4 * HW;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -454,9 +659,14 @@ __global__ __launch_bounds__(512) void swin_mlp_block_kernel(const rsa_swin_mlp_
       for (int pt = 0; pt < 4; ++pt) {
         const int64_t pix = token_pix(16 * pt + li);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (pix >= 0 && g < p4) {
-          v = a[c][pt] + b + x_img[(int64_t)g * HW + pix];
-          o_img[(int64_t)g * HW + pix] = v;
+        if (RSA_SB_ABL & 16) {
+          asm volatile("" ::"v"(a[c][pt]));
+        } else if (pix >= 0 && g < p4) {
+          v = a[c][pt] + b + res[c][pt];
+          if (RSA_SB_ABL & 128)
+            asm volatile("" ::"v"(v));
+          else
+            o_img[MAPIDX(g, pix)] = v;
         }
         a[c][pt] = v;
       }
@@ -498,11 +708,11 @@ extern "C" int rsa_swin_attn_block(const rsa_swin_attn_block_params* p, void* st
       !aligned16(p->wproj) || !aligned16(p->bproj) || !aligned16(p->out))
     return set_error(RSA_E_ALIGN, "swin_attn_block: pointers must be 16-byte aligned");
   const int64_t windows = (int64_t)p->batch * (p->H / p->window) * (p->W / p->window);
-  if (windows > 0x7fffffff) return set_error(RSA_E_UNSUPPORTED, "swin_attn_block: too many windows");
+  if (windows > 0x3fffffff) return set_error(RSA_E_UNSUPPORTED, "swin_attn_block: too many windows");
   if (p->products == 3)
-    hipLaunchKernelGGL(swin_attn_block_kernel<3>, dim3((unsigned)windows), dim3(64 * p->heads), 0, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL(swin_attn_block_kernel<3>, dim3((unsigned)windows), dim3(64 * ((p->heads + 1) / 2)), 0, (hipStream_t)stream, *p);
   else
-    hipLaunchKernelGGL(swin_attn_block_kernel<1>, dim3((unsigned)windows), dim3(64 * p->heads), 0, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL(swin_attn_block_kernel<1>, dim3((unsigned)windows), dim3(64 * ((p->heads + 1) / 2)), 0, (hipStream_t)stream, *p);
   const int rc = (int)hipGetLastError();
   return rc ? set_error(rc, "swin_attn_block: launch failed") : RSA_OK;
 }
@@ -518,7 +728,7 @@ extern "C" int rsa_swin_mlp_block(const rsa_swin_mlp_block_params* p, void* stre
       !aligned16(p->out) || !aligned16(p->out_hi) || !aligned16(p->out_lo))
     return set_error(RSA_E_ALIGN, "swin_mlp_block: pointers must be 16-byte aligned");
   const int64_t tiles = (int64_t)p->batch * (((int64_t)p->H * p->W + SB_TOK - 1) / SB_TOK);
-  if (tiles > 0x7fffffff) return set_error(RSA_E_UNSUPPORTED, "swin_mlp_block: too many tokens");
+  if (tiles > 0x3fffffff) return set_error(RSA_E_UNSUPPORTED, "swin_mlp_block: too many tokens");
   if (p->products == 3)
     hipLaunchKernelGGL(swin_mlp_block_kernel<3>, dim3((unsigned)tiles), dim3(512), 0, (hipStream_t)stream, *p);
   else
