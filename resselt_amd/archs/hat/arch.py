@@ -21,7 +21,7 @@ import math
 import torch
 
 from ...engine import lib as L
-from ...engine import ops
+from ...engine import ops, swinblocks
 from ...engine.base import EngineModule, Plan
 from ...engine.paramtree import build_param_tree
 from ..dat.arch import attn_tiles
@@ -131,6 +131,7 @@ def hat_param_shapes(in_chans, embed_dim, depths, num_heads, window, compress_ra
 
 class HAT(EngineModule):
     hyperparameters = {}
+    fused_mlp = True  # LayerNorm + fc1 + GELU + fc2 + shortcut as one launch where the widths allow it (engine/swinblocks.py)
 
     def __init__(self, *, img_size=64, patch_size=1, in_chans=3, embed_dim=96, depths=(6, 6, 6, 6), num_heads=(6, 6, 6, 6), window_size=7,
                  compress_ratio=3, squeeze_factor=30, conv_scale=0.01, overlap_ratio=0.5, mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
@@ -292,7 +293,8 @@ class HAT(EngineModule):
         a_pl = plan.planes(n, cp, H, Wd, with_lo)
         qkv_pl = plan.planes(n, 3 * max_heads * HEAD_PAD // 8, H, Wd, with_lo)
         o_pl = plan.planes(n, max_heads * HEAD_PAD // 8, H, Wd, with_lo)
-        hid_pl = plan.planes(n, (hidden + 7) // 8, H, Wd, with_lo)
+        fuse_mlp = self.fused_mlp and swinblocks.mlp_block_fits(C_, hidden)
+        hid_pl = None if fuse_mlp else plan.planes(n, (hidden + 7) // 8, H, Wd, with_lo)
         body_pl = plan.planes(n, cp, H, Wd, with_lo)
         cab_a = plan.planes(n, (self.compress + 7) // 8, H, Wd, with_lo)
         cab_b = plan.planes(n, cp, H, Wd, with_lo)
@@ -347,6 +349,9 @@ class HAT(EngineModule):
             plan.count_launches(1)
 
         def mlp(b, x1, x2, out_planes=None):
+            if fuse_mlp:  # one launch (csrc/swin_block.hip), nothing between leaves the chip
+                swinblocks.mlp_block(plan, W[f'{b}.norm2'], W[f'{b}.mlp.fc1'], W[f'{b}.mlp.fc2'], n, H, Wd, C_, hidden, products, x1, x2, out_planes)
+                return
             layernorm(f'{b}.norm2', x1, out_planes=a_pl)
             plan.conv(ops.conv_params(W[f'{b}.mlp.fc1'], a_pl, H, Wd, cin_planes=cp, act=L.ACT_GELU, out=hid_pl))
             plan.conv(ops.conv_params(W[f'{b}.mlp.fc2'], hid_pl, H, Wd, cin_planes=(hidden + 7) // 8, res1=x1, alpha=1.0, out_f32=x2, out=out_planes))

@@ -19,7 +19,7 @@ import math
 import torch
 
 from ...engine import lib as L
-from ...engine import ops
+from ...engine import ops, swinblocks
 from ...engine.base import EngineModule, Plan
 from ...engine.paramtree import build_param_tree
 
@@ -338,7 +338,7 @@ class SwinIR(EngineModule):
         max_heads = max(self.num_heads)
 
         def can_fuse(heads):
-            return self.fused_blocks and C_ <= 256 and heads <= 8 and C_ // heads <= HEAD_PAD and hidden <= 512
+            return self.fused_blocks and swinblocks.mlp_block_fits(C_, hidden) and heads <= 8 and C_ // heads <= HEAD_PAD
 
         if all(can_fuse(h) for h in self.num_heads):
             qkv_pl = o_pl = hid_pl = None  # nothing between the residual stream and itself leaves the chip
@@ -388,20 +388,8 @@ class SwinIR(EngineModule):
             plan.count_launches(1)
 
         def mlp_block(name, x_f32, out_f32, out_planes=None):
-            """norm2 -> fc1 -> GELU -> fc2 -> + shortcut in one launch (arch.py:331-335)."""
-            g, be = W[f'{name}.norm2']
-            fc1, fc2 = W[f'{name}.mlp.fc1'], W[f'{name}.mlp.fc2']
-            mp = L.SwinMlpBlockParams()
-            mp.batch, mp.H, mp.W, mp.C, mp.hidden, mp.products, mp.eps = n, H, Wd, C_, hidden, products, 1e-5
-            mp.x, mp.gamma, mp.beta = x_f32.data_ptr(), g.data_ptr(), be.data_ptr()
-            mp.w1, mp.b1 = fc1.packed_for(0).data_ptr(), fc1.bias.data_ptr()
-            mp.w2, mp.b2 = fc2.packed_for(0).data_ptr(), fc2.bias.data_ptr()
-            mp.out = out_f32.data_ptr()
-            if out_planes is not None:
-                mp.out_hi, mp.out_lo = out_planes.hi_ptr(), out_planes.lo_ptr()
-                mp.out_plane_stride, mp.out_batch_stride = out_planes.plane_stride, out_planes.batch_stride
-            plan.call(lambda: L.check(lib.rsa_swin_mlp_block(C.byref(mp), C.c_void_p(ops.current_stream_ptr(dev))), 'rsa_swin_mlp_block'))
-            plan.count_launches(1)
+            swinblocks.mlp_block(plan, W[f'{name}.norm2'], W[f'{name}.mlp.fc1'], W[f'{name}.mlp.fc2'], n, H, Wd, C_, hidden, products, x_f32, out_f32,
+                                 out_planes)  # fmt: skip
 
         def resi_conv(name, src_planes, res, out_f32=None, out_planes=None):
             """1conv / 3conv tail (arch.py:562-574) + the residual add that follows it."""
