@@ -237,29 +237,6 @@ __device__ __forceinline__ void frag_of(const f32x4 a, const f32x4 b, bf16x8& hi
   lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
 }
 
-// GELU(x) = x/2 * (1 + erf(x / sqrt 2)) with erf as the rational x * P(x^2) / Q(x^2) on [-4, 4] (the f32 approximation used by the
-// tensor libraries; |error| of erf <= 4.5e-7, of GELU <= 2.5e-7 * max(1, |x|)): 17 instructions and no branch, against the two-branch
-// erff of the device library (the MLP's hidden map costs 64 GELUs per lane and tile, beside 96 MFMAs).
-__device__ __forceinline__ float gelu_fast(float x) {
-  const float t = __builtin_amdgcn_fmed3f(x * 0.70710678118654752440f, -4.f, 4.f);
-  const float t2 = t * t;
-  float pn = -2.72614225801306e-10f;
-  pn = fmaf(pn, t2, 2.77068142495902e-08f);
-  pn = fmaf(pn, t2, -2.10102402082508e-06f);
-  pn = fmaf(pn, t2, -5.69250639462346e-05f);
-  pn = fmaf(pn, t2, -7.34990630326855e-04f);
-  pn = fmaf(pn, t2, -2.95459980854025e-03f);
-  pn = fmaf(pn, t2, -1.60960333262415e-02f);
-  float qd = -1.45660718464996e-05f;
-  qd = fmaf(qd, t2, -2.13374055278905e-04f);
-  qd = fmaf(qd, t2, -1.68282697438203e-03f);
-  qd = fmaf(qd, t2, -7.37332916720468e-03f);
-  qd = fmaf(qd, t2, -1.42647390514189e-02f);
-  const float e = pn * t * __builtin_amdgcn_rcpf(qd);
-  const float hx = 0.5f * x;
-  return fmaf(hx, e, hx);
-}
-
 template <int PROD>
 __device__ __forceinline__ f32x4 mfma3(const bf16x8 ah, const bf16x8 al, const bf16x8 bh, const bf16x8 bl, f32x4 c) {
   if (PROD == 3) {
