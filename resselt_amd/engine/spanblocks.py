@@ -73,7 +73,10 @@ class SpabChain:
         self.t1 = plan.planes(n, self.pf, h, w, with_lo)
         self.t2 = plan.planes(n, self.pf, h, w, with_lo)
         self.ping = [plan.planes(n, self.pf, h, w, with_lo) for _ in range(2)]
-        self.f32 = [plan.f32map(n, fc, h, w) for _ in range(3)]
+        # The gate's shortcut is read from the block input's own split planes (value = hi + lo, 16 bits) in bf16x3 mode: no f32 copy of
+        # every block output is written and read back (-12 % of a SPAB's bytes).  Plain-bf16 mode has no lo planes and keeps the f32 maps.
+        self.plane_shortcut = with_lo
+        self.f32 = [None] * 3 if self.plane_shortcut else [plan.f32map(n, fc, h, w) for _ in range(3)]
 
     def new_cat(self) -> Planes:
         return self.plan.planes(self.n, 4 * self.pf, self.h, self.w, self.with_lo)
@@ -87,7 +90,10 @@ class SpabChain:
         a1, a1_off = out1 if out1 is not None else (self.t1, 0)
         self._conv(f'{name}.c1_r', x, in_plane0=x_plane0, act=self.act, out=a1, out_plane_off=a1_off)
         self._conv(f'{name}.c2_r', a1, in_plane0=a1_off, act=self.act, out=self.t2)
-        self._conv(f'{name}.c3_r', self.t2, act=L.ACT_SPAB_GATE, res1=xf, out=out, out_plane_off=out_plane0, out_f32=out_f32)
+        if self.plane_shortcut:
+            self._conv(f'{name}.c3_r', self.t2, act=L.ACT_SPAB_GATE, res1=(x, x_plane0), out=out, out_plane_off=out_plane0)
+        else:
+            self._conv(f'{name}.c3_r', self.t2, act=L.ACT_SPAB_GATE, res1=xf, out=out, out_plane_off=out_plane0, out_f32=out_f32)
 
     def run(self, names: dict, cat: Planes, xf: torch.Tensor, out: Planes, out_plane0: int, out_f32: torch.Tensor | None) -> None:
         """``cat`` slot 0 already holds x (split planes) and ``xf`` its f32 map; result of conv_cat goes to ``out``."""
