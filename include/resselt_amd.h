@@ -321,6 +321,42 @@ typedef struct rsa_swin_mlp_block_params {
 
 int rsa_swin_mlp_block(const rsa_swin_mlp_block_params* p, void* stream);
 
+/* rsa_swin_block: both halves in one launch -- out = x1 + fc2(GELU(fc1(norm2(x1)))), x1 = x + proj(window_attention(qkv(norm1(x))))
+ * (SwinTransformerBlock.forward, resselt/archs/swinir/arch.py:295-335).  x1 stays in registers: the residual stream is read once and
+ * written once per block.  Operands and limits as for the two half launches above (resselt_amd/csrc/swin_block_full.hip). */
+typedef struct rsa_swin_block_params {
+  int32_t batch;
+  int32_t H, W;            /* multiples of `window` */
+  int32_t C;
+  int32_t heads;
+  int32_t window;          /* <= 8 */
+  int32_t shift;           /* 0 or window/2 */
+  int32_t hidden;
+  int32_t products;        /* 1 or 3 */
+  float eps;
+  const float* x;          /* f32 NCHW4c */
+  const float* gamma1;     /* norm1 */
+  const float* beta1;
+  const void* wqkv;
+  const float* bqkv;
+  const float* bias_frag16;
+  const void* wproj;
+  const float* bproj;
+  const float* gamma2;     /* norm2 */
+  const float* beta2;
+  const void* w1;
+  const float* b1;
+  const void* w2;
+  const float* b2;
+  float* out;              /* f32 NCHW4c; may be x */
+  void* out_hi;            /* optional split-plane copy of the result */
+  void* out_lo;
+  int64_t out_plane_stride; /* 16-byte units */
+  int64_t out_batch_stride;
+} rsa_swin_block_params;
+
+int rsa_swin_block(const rsa_swin_block_params* p, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------- DAT ops
  * Building blocks of the Dual Aggregation Transformer path (reference archs/dat/arch.py).  Tokens are pixels; every map is in
  * the split-plane layout [N][planes][H][W][8] (bf16 hi, optional lo).  Attention maps use the head-padded channel layout of

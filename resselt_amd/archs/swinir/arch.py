@@ -194,9 +194,10 @@ def swinir_param_shapes(in_ch, out_ch, embed_dim, depths, num_heads, window, mlp
 
 class SwinIR(EngineModule):
     hyperparameters = {}
-    # One launch per block half (csrc/swin_block.hip) where the shapes allow it; False = the layer-by-layer path (LayerNorm, Linear
-    # layers as k1 convolutions, rsa_window_attention), kept for widths the fused kernels do not take and for A/B runs.
-    fused_blocks = True
+    # 'whole': one launch per block (csrc/swin_block_full.hip); 'halves': one launch per block half (csrc/swin_block.hip); False: the
+    # layer-by-layer path (LayerNorm, Linear layers as k1 convolutions, rsa_window_attention).  The fused kernels take C <= 256,
+    # <= 8 heads of <= 32 channels, window <= 8, hidden <= 512; other widths run layer by layer whatever this says.
+    fused_blocks = 'whole'
 
     def __init__(self, *, img_size=64, patch_size=1, in_chans=3, embed_dim=96, depths=(6, 6, 6, 6), num_heads=(6, 6, 6, 6), window_size=7,
                  mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1, ape=False,
@@ -387,6 +388,25 @@ class SwinIR(EngineModule):
             plan.call(lambda: L.check(lib.rsa_swin_attn_block(C.byref(ap), C.c_void_p(ops.current_stream_ptr(dev))), 'rsa_swin_attn_block'))
             plan.count_launches(1)
 
+        def whole_block(name, heads, shift, x_f32, out_f32, out_planes=None):
+            """The whole block in one launch (arch.py:295-335; csrc/swin_block_full.hip): x1 never leaves the chip."""
+            g1, be1 = W[f'{name}.norm1']
+            g2, be2 = W[f'{name}.norm2']
+            qkv, proj, fc1, fc2 = (W[f'{name}.{k}'] for k in ('attn.qkv', 'attn.proj', 'mlp.fc1', 'mlp.fc2'))
+            bp = L.SwinBlockParams()
+            bp.batch, bp.H, bp.W, bp.C, bp.heads, bp.window, bp.shift, bp.hidden, bp.products, bp.eps = n, H, Wd, C_, heads, win, shift, hidden, products, 1e-5
+            bp.x, bp.gamma1, bp.beta1, bp.gamma2, bp.beta2 = x_f32.data_ptr(), g1.data_ptr(), be1.data_ptr(), g2.data_ptr(), be2.data_ptr()
+            bp.wqkv, bp.bqkv = qkv.packed_for(0).data_ptr(), qkv.bias.data_ptr()
+            bp.bias_frag16 = W[f'{name}.bias_frag16'].data_ptr()
+            bp.wproj, bp.bproj = proj.packed_for(0).data_ptr(), proj.bias.data_ptr()
+            bp.w1, bp.b1, bp.w2, bp.b2 = fc1.packed_for(0).data_ptr(), fc1.bias.data_ptr(), fc2.packed_for(0).data_ptr(), fc2.bias.data_ptr()
+            bp.out = out_f32.data_ptr()
+            if out_planes is not None:
+                bp.out_hi, bp.out_lo = out_planes.hi_ptr(), out_planes.lo_ptr()
+                bp.out_plane_stride, bp.out_batch_stride = out_planes.plane_stride, out_planes.batch_stride
+            plan.call(lambda: L.check(lib.rsa_swin_block(C.byref(bp), C.c_void_p(ops.current_stream_ptr(dev))), 'rsa_swin_block'))
+            plan.count_launches(1)
+
         def mlp_block(name, x_f32, out_f32, out_planes=None):
             swinblocks.mlp_block(plan, W[f'{name}.norm2'], W[f'{name}.mlp.fc1'], W[f'{name}.mlp.fc2'], n, H, Wd, C_, hidden, products, x_f32, out_f32,
                                  out_planes)  # fmt: skip
@@ -417,7 +437,10 @@ class SwinIR(EngineModule):
                 shift = 0 if j % 2 == 0 else win // 2
                 last = j == depth - 1
                 x1 = free.pop()
-                if can_fuse(heads):
+                if can_fuse(heads) and self.fused_blocks == 'whole':
+                    x2 = free.pop()
+                    whole_block(b, heads, shift, cur, x2, body_pl if last else None)
+                elif can_fuse(heads):
                     attn_block(b, heads, shift, cur, x1)
                     x2 = free.pop()
                     mlp_block(b, x1, x2, body_pl if last else None)

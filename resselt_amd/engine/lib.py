@@ -162,6 +162,42 @@ class SwinMlpBlockParams(C.Structure):
     ]
 
 
+class SwinBlockParams(C.Structure):
+    """Mirror of ``struct rsa_swin_block_params``."""
+
+    _fields_ = [
+        ('batch', C.c_int32),
+        ('H', C.c_int32),
+        ('W', C.c_int32),
+        ('C', C.c_int32),
+        ('heads', C.c_int32),
+        ('window', C.c_int32),
+        ('shift', C.c_int32),
+        ('hidden', C.c_int32),
+        ('products', C.c_int32),
+        ('eps', C.c_float),
+        ('x', C.c_void_p),
+        ('gamma1', C.c_void_p),
+        ('beta1', C.c_void_p),
+        ('wqkv', C.c_void_p),
+        ('bqkv', C.c_void_p),
+        ('bias_frag16', C.c_void_p),
+        ('wproj', C.c_void_p),
+        ('bproj', C.c_void_p),
+        ('gamma2', C.c_void_p),
+        ('beta2', C.c_void_p),
+        ('w1', C.c_void_p),
+        ('b1', C.c_void_p),
+        ('w2', C.c_void_p),
+        ('b2', C.c_void_p),
+        ('out', C.c_void_p),
+        ('out_hi', C.c_void_p),
+        ('out_lo', C.c_void_p),
+        ('out_plane_stride', C.c_int64),
+        ('out_batch_stride', C.c_int64),
+    ]
+
+
 class WindowAttnParams(C.Structure):
     """Mirror of ``struct rsa_window_attn_params``."""
 
@@ -369,6 +405,7 @@ EXPORTS = (
     'rsa_window_attention',
     'rsa_swin_attn_block',
     'rsa_swin_mlp_block',
+    'rsa_swin_block',
     'rsa_rect_attention',
     'rsa_channel_attn_workspace_bytes',
     'rsa_channel_attention_weights',
@@ -463,6 +500,8 @@ def load() -> C.CDLL:
     lib.rsa_swin_attn_block.restype = C.c_int
     lib.rsa_swin_mlp_block.argtypes = [C.POINTER(SwinMlpBlockParams), C.c_void_p]
     lib.rsa_swin_mlp_block.restype = C.c_int
+    lib.rsa_swin_block.argtypes = [C.POINTER(SwinBlockParams), C.c_void_p]
+    lib.rsa_swin_block.restype = C.c_int
     for name, struct in (('rsa_rect_attention', RectAttnParams), ('rsa_channel_attention_weights', ChannelAttnParams), ('rsa_dwconv3x3', DwConvParams),
                          ('rsa_channel_gate', ChannelGateParams), ('rsa_aim_combine', AimParams)):  # fmt: skip
         getattr(lib, name).argtypes = [C.POINTER(struct), C.c_void_p]

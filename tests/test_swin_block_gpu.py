@@ -165,6 +165,65 @@ def test_block_halves_compose_to_the_oracle_block(device):
         assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
+def _run_block(sd, x, heads, window, shift, hidden, products, device, planes=False, inplace=False):
+    n, C_, H, W = x.shape
+    xm = tensors.nchw_to_f32map(x.to(device))
+    out = xm if inplace else torch.full_like(xm, float('nan'))
+    wq, bq = regroup_qkv(sd['b.attn.qkv.weight'], sd['b.attn.qkv.bias'], heads)
+    qkv = _lin(wq, bq, products, device)
+    proj = _lin(regroup_proj(sd['b.attn.proj.weight'], heads), sd['b.attn.proj.bias'], products, device, cin_planes=heads * 4)
+    fc1 = _lin(sd['b.mlp.fc1.weight'], sd['b.mlp.fc1.bias'], products, device)
+    fc2 = _lin(sd['b.mlp.fc2.weight'], sd['b.mlp.fc2.bias'], products, device)
+    frag = bias_fragments16(sd['b.attn.relative_position_bias_table'], sd['b.attn.relative_position_index'], window).to(device)
+    g1, be1, g2, be2 = (sd[k].to(device) for k in ('b.norm1.weight', 'b.norm1.bias', 'b.norm2.weight', 'b.norm2.bias'))
+    bp = L.SwinBlockParams()
+    bp.batch, bp.H, bp.W, bp.C, bp.heads, bp.window, bp.shift, bp.hidden, bp.products, bp.eps = n, H, W, C_, heads, window, shift, hidden, products, 1e-5
+    bp.x, bp.gamma1, bp.beta1, bp.gamma2, bp.beta2 = xm.data_ptr(), g1.data_ptr(), be1.data_ptr(), g2.data_ptr(), be2.data_ptr()
+    bp.wqkv, bp.bqkv, bp.bias_frag16 = qkv.packed_for(0).data_ptr(), qkv.bias.data_ptr(), frag.data_ptr()
+    bp.wproj, bp.bproj = proj.packed_for(0).data_ptr(), proj.bias.data_ptr()
+    bp.w1, bp.b1, bp.w2, bp.b2 = fc1.packed_for(0).data_ptr(), fc1.bias.data_ptr(), fc2.packed_for(0).data_ptr(), fc2.bias.data_ptr()
+    bp.out = out.data_ptr()
+    pl = None
+    if planes:
+        pl = tensors.Planes.empty(n, (C_ + 7) // 8, H, W, device, with_lo=products == 3)
+        pl.hi.fill_(float('nan'))
+        bp.out_hi, bp.out_lo, bp.out_plane_stride, bp.out_batch_stride = pl.hi_ptr(), pl.lo_ptr(), pl.plane_stride, pl.batch_stride
+    L.check(L.load().rsa_swin_block(C.byref(bp), C.c_void_p(ops.current_stream_ptr(device))), 'rsa_swin_block')
+    torch.cuda.synchronize()
+    return tensors.f32map_to_nchw(out, C_).cpu(), pl
+
+
+@pytest.mark.parametrize('products', [3, 1])
+@pytest.mark.parametrize(
+    'n,C_,heads,hidden,window,shift,h,w',
+    [
+        (1, 240, 8, 480, 8, 0, 16, 24),   # SwinIR-L
+        (1, 240, 8, 480, 8, 4, 24, 16),   # ... shifted
+        (2, 180, 6, 360, 8, 4, 16, 16),   # SwinIR-M: two waves without a head, 23 hidden tiles, 12 output tiles
+        (1, 60, 6, 120, 8, 4, 16, 8),     # lightweight: head_dim 10, 15 of 16 channel groups per wave pair live
+        (1, 96, 6, 384, 7, 3, 14, 21),    # window 7: 49 tokens (padded keys / queries / LayerNorm rows), mlp_ratio 4
+        (1, 64, 2, 128, 4, 2, 8, 12),     # window 4, two heads
+        (1, 256, 8, 512, 8, 4, 8, 8),     # the widest shape; one window with every mask region
+    ],
+)
+def test_whole_block_kernel(device, n, C_, heads, hidden, window, shift, h, w, products):
+    from oracle.swinir import swin_block
+
+    sd = _block_sd(C_, heads, hidden, window, 400 + C_ + window)
+    x = _rand((n, C_, h, w), 13, 2.0) + 0.3
+    ref = swin_block(sd, 'b', x.permute(0, 2, 3, 1).reshape(n, h * w, C_), h, w, window, shift, heads).reshape(n, h, w, C_).permute(0, 3, 1, 2)
+    got, pl = _run_block(sd, x, heads, window, shift, hidden, products, device, planes=True)
+    scale = ref.abs().max().item()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= (3e-5 if products == 3 else 4e-2) * scale
+    full = tensors.planes_to_nchw(pl, pl.planes * 8).cpu()
+    assert (full[:, :C_] - ref).abs().max().item() <= (3e-5 if products == 3 else 5e-2) * scale
+    if pl.planes * 8 > C_:
+        assert full[:, C_:].abs().max().item() == 0.0
+    got2, _ = _run_block(sd, x, heads, window, shift, hidden, products, device, inplace=True)
+    assert torch.equal(got2, got)
+
+
 def test_block_kernels_reject_unsupported_shapes(device):
     lib = L.load()
     ap = L.SwinAttnBlockParams()
@@ -173,3 +232,6 @@ def test_block_kernels_reject_unsupported_shapes(device):
     mp = L.SwinMlpBlockParams()
     mp.batch, mp.H, mp.W, mp.C, mp.hidden, mp.products = 1, 8, 8, 240, 960, 3
     assert lib.rsa_swin_mlp_block(C.byref(mp), None) == -2  # RSA_E_UNSUPPORTED
+    bp = L.SwinBlockParams()
+    bp.batch, bp.H, bp.W, bp.C, bp.heads, bp.window, bp.shift, bp.hidden, bp.products = 1, 16, 16, 240, 8, 16, 0, 480, 3
+    assert lib.rsa_swin_block(C.byref(bp), None) == -2  # window 16 (256 tokens) is the rect-attention path's

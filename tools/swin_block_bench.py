@@ -56,6 +56,17 @@ def mlp():
     return lambda: L.check(lib.rsa_swin_mlp_block(C.byref(mp), st), 'mlp')
 
 
+def whole(shift):
+    bp = L.SwinBlockParams()
+    bp.batch, bp.H, bp.W, bp.C, bp.heads, bp.window, bp.shift, bp.hidden, bp.products, bp.eps = 1, H, W, C_, heads, win, shift, hidden, 3, 1e-5
+    bp.x, bp.gamma1, bp.beta1, bp.gamma2, bp.beta2 = x.data_ptr(), ga.data_ptr(), be.data_ptr(), ga.data_ptr(), be.data_ptr()
+    bp.wqkv, bp.bqkv, bp.bias_frag16 = qkv.packed_for(0).data_ptr(), qkv.bias.data_ptr(), frag.data_ptr()
+    bp.wproj, bp.bproj = proj.packed_for(0).data_ptr(), proj.bias.data_ptr()
+    bp.w1, bp.b1, bp.w2, bp.b2 = fc1.packed_for(0).data_ptr(), fc1.bias.data_ptr(), fc2.packed_for(0).data_ptr(), fc2.bias.data_ptr()
+    bp.out = out.data_ptr()
+    return lambda: L.check(lib.rsa_swin_block(C.byref(bp), st), 'block')
+
+
 def timed(fn, reps=20):
     for _ in range(3):
         fn()
@@ -73,6 +84,7 @@ tok = H * W
 hd = C_ // heads
 flop_attn = 2 * tok * (3 * C_ * C_ + C_ * C_ + 2 * 64 * C_)
 flop_mlp = 2 * tok * 2 * C_ * hidden
-for name, fn, fl in (('attn shift 0', attn(0), flop_attn), ('attn shift 4', attn(4), flop_attn), ('mlp', mlp(), flop_mlp)):
+for name, fn, fl in (('attn shift 0', attn(0), flop_attn), ('attn shift 4', attn(4), flop_attn), ('mlp', mlp(), flop_mlp),
+                     ('whole block shift 0', whole(0), flop_attn + flop_mlp), ('whole block shift 4', whole(4), flop_attn + flop_mlp)):
     ms = timed(fn)
     print(f'{name}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TF algorithmic, {3 * fl / ms / 1e9:.0f} TF issued (bf16x3)', flush=True)
