@@ -143,3 +143,25 @@ def test_swinir_L_vs_oracle_bf16_input(device):
     e1 = (m(x.to(device)).cpu() - ref).abs().max().item()
     print(f'SwinIR-L(3x6) plain bf16 max-abs {e1:.3e}')
     assert e1 <= 5e-2 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('window,embed,heads', [(8, 240, 8), (7, 96, 6)])
+def test_swinir_block_paths_agree(device, window, embed, heads):
+    """The three ways a block can run -- one launch ('whole', csrc/swin_block_full.hip), one per half ('halves', csrc/swin_block.hip)
+    and layer by layer (False) -- against the oracle and against each other on the same model."""
+    sd = synth.swinir_state_dict(embed_dim=embed, depths=[2, 2], num_heads=[heads, heads], window=window, upscale=2,
+                                 upsampler='pixelshuffle', resi='1conv', img_size=8 * window, seed=11)  # fmt: skip
+    x = synth.synth_input((1, 3, 5 * window + 3, 4 * window), seed=12)
+    with torch.no_grad():
+        ref = oracle_forward(dict(arch='swinir'), sd, x)
+    m = resselt_amd.load_from_state_dict(dict(sd)).to(device)
+    outs = {}
+    for mode in ('whole', 'halves', False):
+        m.fused_blocks = mode
+        m.invalidate()
+        outs[mode] = m(x.to(device)).cpu()
+        launches = m.launches_per_forward()
+        assert (outs[mode] - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item()), mode
+        outs[mode, 'launches'] = launches
+    assert outs['whole', 'launches'] < outs['halves', 'launches'] < outs[False, 'launches']
+    assert (outs['whole'] - outs[False]).abs().max().item() <= 5e-5 * max(1.0, ref.abs().max().item())
