@@ -16,7 +16,13 @@ template <int PROD>
 __global__ __launch_bounds__(512) void swin_block_kernel(const rsa_swin_block_params p) {
   constexpr int HPL = 64;  // planes of the LDS image (512 hidden channels); the token / attention-output images use planes 0..31
   constexpr int LO0 = HPL * SB_TOK;
-  constexpr int RED0 = 32 * SB_TOK;  // LayerNorm-2 partial sums: hi planes 32..35 (free until the hidden image is written)
+  // While the token / attention-output images are in use (hi planes 0..31, lo planes 64..95) the other half of the array is free:
+  // the raw f32 rows norm1 loaded are parked there ([channel group][token], groups 0..31 in hi planes 32..63, groups 32..59 in lo
+  // planes 96..123) and come back as proj's shortcut -- the residual stream is fetched from memory exactly once per block (15 us
+  // after norm1 read them the lines have left the L2: measured 1 GB of re-fetch per launch).  Widths above 240 channels have no
+  // room for that and read the shortcut from memory.  norm2's partial sums: lo planes 124..127.
+  constexpr int STASH0 = 32 * SB_TOK, STASH1 = 96 * SB_TOK;
+  constexpr int RED0 = 124 * SB_TOK;
   constexpr int NHL = PROD == 3 ? 2 : 1;
   __shared__ uint4 s_h[2 * HPL * SB_TOK];  // 128 KB
 
@@ -64,11 +70,21 @@ __global__ __launch_bounds__(512) void swin_block_kernel(const rsa_swin_block_pa
   for (int c = 0; c < 2; ++c) woff_2[c] = (2 * wave + c < ct_c) ? (uint32_t)(((2 * wave + c) * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
   W0<PROD, 4> w0qk;
   w0_load<PROD, 4>(w0qk, rq, woff_qk);
+  const bool stash = p4 <= 60;
   {
     const int t = wave * 8 + (lane & 7);
     const int64_t pix = token_pix(t);
     LnRow row;
     ln_load(row, x_img, HW, p4, pix, lane);
+    if (stash) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int g = ((lane >> 3) + 8 * i) * 2 + h;
+          if (g < p4) s_h[(g < 32 ? STASH0 + g * SB_TOK : STASH1 + (g - 32) * SB_TOK) + t] = __builtin_bit_cast(uint4, row.v[i][h]);
+        }
+    }
     ln_store<PROD>(row, s_h, LO0, 4 * nk, p.C, p.gamma1, p.beta1, p.eps, t, pix, lane);
   }
   __syncthreads();
@@ -194,17 +210,22 @@ __global__ __launch_bounds__(512) void swin_block_kernel(const rsa_swin_block_pa
         if (PROD == 3) s_h[LO0 + u] = oul[dt * 2 + k];
       }
   }
-  // the shortcut of proj's epilogue is requested ahead of the barrier and the multiply (the lines norm1 read: L2 hits); from the
-  // epilogue on the same registers hold x1: [cout tile 2*wave + c][token tile]
+  // the shortcut of proj's epilogue: from the parked rows, or (wide models) requested from memory ahead of the barrier and the
+  // multiply; from the epilogue on the same registers hold x1: [cout tile 2*wave + c][token tile]
   f32x4 x1[2][4];
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
       const int g = (2 * wave + c) * 4 + lg;
-      const int64_t px = token_pix(16 * pt + li);
+      const int t = 16 * pt + li;
       x1[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (px >= 0 && g < p4) x1[c][pt] = x_img[(int64_t)g * HW + px];
+      if (stash) {
+        if (t < ntok && g < p4) x1[c][pt] = __builtin_bit_cast(f32x4, s_h[(g < 32 ? STASH0 + g * SB_TOK : STASH1 + (g - 32) * SB_TOK) + t]);
+      } else {
+        const int64_t px = token_pix(t);
+        if (px >= 0 && g < p4) x1[c][pt] = x_img[(int64_t)g * HW + px];
+      }
     }
   __syncthreads();
 
