@@ -112,7 +112,7 @@ typedef struct rsa_conv_params {
   void* out_nchw;           /* final plain tensor [N][cout/r^2][H*r][W*r], dtype out_dtype -- or, for RSA_U8, the 8-bit image
                                [N][H*r][W*r][cout/r^2]; exclusive with out_hi/out_f32/res1/res2 (separate kernel instantiation) */
   int32_t out_dtype;        /* enum rsa_dtype */
-  int32_t pixel_shuffle;    /* r >= 1 (depth-to-space factor applied while storing out_nchw) */
+  int32_t pixel_shuffle;    /* r >= 1 (depth-to-space factor applied while storing out_nchw; r > 1: out_nchw 16-byte aligned) */
   float out_scale;          /* out_nchw value = v * out_scale + out_shift[oc]  (SwinIR x/img_range + mean, */
   const float* out_shift;   /*   archs/swinir/arch.py:1013); NULL = none */
   const float* act_vec;     /* RSA_ACT_PRELU: negative slopes, f32[round_up(cout,16)], 16-byte aligned */

@@ -3,6 +3,8 @@
 
 namespace rsa {
 int conv_launch_ring3(const rsa_conv_params& p, hipStream_t stream) {
+  if (p.out_nchw != nullptr)  // final store (NCHW any dtype / 8-bit image, depth-to-space, affine): the x4 pixel-shuffle heads
+    return (p.cin_planes & 3) ? launch_ring<3, 0, 1, 1>(p, stream) : launch_ring<3, 0, 1, 0>(p, stream);
   return (p.cin_planes & 3) ? launch_ring<3, 0, 0, 1>(p, stream) : launch_ring<3, 0, 0, 0>(p, stream);  // half mode for 1.5, 2.5 ... chunks
 }
 #ifdef RSA_RING_DEBUG

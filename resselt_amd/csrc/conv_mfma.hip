@@ -34,7 +34,7 @@ bool conv_ring_enabled() {
 const char* conv_kernel_name(const rsa_conv_params& p) {
   if (p.w_layout != RSA_WL_TAPS) {
     const int ct = (p.cout + 15) >> 4;
-    return ct == 2 ? "rsa::conv_ring<2,UP,0> (Cout<=32)" : ct == 3 ? "rsa::conv_ring<3,0,0,HM> (Cout 33..48)" : "rsa::conv_ring<1,UP,0> (Cout 49..64)";
+    return ct == 2 ? "rsa::conv_ring<2,UP,0> (Cout<=32)" : ct == 3 ? (p.out_nchw != nullptr ? "rsa::conv_ring<3,0,1,HM> (Cout 33..48, final store)" : "rsa::conv_ring<3,0,0,HM> (Cout 33..48)") : "rsa::conv_ring<1,UP,0> (Cout 49..64)";
   }
   if (p.ksize == 1 && p.cout >= 96 && p.out_nchw == nullptr) return "rsa::gemm_k1_kernel";
   if (p.ksize == 3 && p.products == 3 && conv_nct(p.cout) == 2 && p.cout <= 32) return "rsa::conv_kernel_pp";
@@ -69,6 +69,7 @@ int conv_launch(const rsa_conv_params& p, hipStream_t stream) {
   if (((uintptr_t)p.in_hi | (uintptr_t)p.in_lo | (uintptr_t)p.w_packed | (uintptr_t)p.out_hi | (uintptr_t)p.out_lo | (uintptr_t)p.out_f32 |
        (uintptr_t)p.res1 | (uintptr_t)p.res2 | (uintptr_t)p.res1_hi | (uintptr_t)p.res1_lo | (uintptr_t)p.res2_hi | (uintptr_t)p.res2_lo) & 15)
     return set_error(RSA_E_ALIGN, "conv: pointers must be 16-byte aligned");
+  if (p.pixel_shuffle > 1 && ((uintptr_t)p.out_nchw & 15)) return set_error(RSA_E_ALIGN, "conv: out_nchw must be 16-byte aligned for a depth-to-space store (vector stores)");
   if (p.in_plane_stride * 64 >= (int64_t)1 << 32) return set_error(RSA_E_UNSUPPORTED, "conv: input plane too large for a 4-plane buffer descriptor (>= 64 Mpx); band the image");
   if (p.out_plane_stride * 32 >= (int64_t)1 << 32 || (int64_t)p.H * p.W * 64 >= (int64_t)1 << 32)
     return set_error(RSA_E_UNSUPPORTED, "conv: output plane too large for 32-bit lane offsets; band the image");
