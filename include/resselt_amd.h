@@ -140,6 +140,8 @@ int rsa_conv2d_list(const rsa_conv_params* list, int32_t n, void* stream);
 
 /* Bytes of the packed weight blob for a (cout, cin_planes, ksize, products) convolution. */
 int64_t rsa_packed_weight_bytes(int32_t cout, int32_t cin_planes, int32_t ksize, int32_t products);
+/* the same for a given layout (layouts 0..2 have the size above; layout 3 is 32 K steps of 4 cout tiles = 256 KiB) */
+int64_t rsa_packed_weight_bytes_layout(int32_t cout, int32_t cin_planes, int32_t ksize, int32_t products, int32_t layout);
 
 /* Number of 16-channel cout tiles one workgroup computes for `cout` output channels (1..4); the grid has
  * ceil(ceil(cout/16) / tiles) slabs in y.  Exposed so host code and tests can reason about launch geometry. */
@@ -154,6 +156,8 @@ int rsa_conv_cout_tiles(int32_t cout);
  *   0  blob[chunk q][tap t][cout_tile][hi|lo][lane 0..63][8] bf16, lane l: cout = 16*tile + (l & 15), cin = 32*q + 8*(l >> 4) + j
  *   1  tap-pair order of the ring schedule (3x3, three products, whole 32-channel chunks): resselt_amd/csrc/pack.hip
  *   2  the same per 16-channel half chunk, five K steps each (an odd number of half chunks, e.g. 48 input channels)
+ *   3  nearest x2 upsampling + 3x3 as four 2x2 phase convolutions on the source map, taps pre-summed (64 -> 64 channels;
+ *      resselt_amd/csrc/conv_ring_up.h)
  * (hi = bf16 RNE of w, lo = bf16 of w - hi; only hi when products == 1).
  */
 int rsa_conv_weight_layout(const rsa_conv_params* p);

@@ -16,7 +16,8 @@ int conv_nct(int cout);
 const char* conv_kernel_name(const rsa_conv_params& p);
 
 // Packed-weight layouts (rsa_pack_weights): 0 = tap-major chunks (conv_kernel.h, gemm_k1.hip), 1 = tap-pair order (conv_ring.h)
-enum { RSA_WL_TAPS = 0, RSA_WL_PAIRS = 1, RSA_WL_HALFPAIRS = 2 };  // 2: the ring schedule's half mode (odd number of half chunks)
+enum { RSA_WL_TAPS = 0, RSA_WL_PAIRS = 1, RSA_WL_HALFPAIRS = 2, RSA_WL_UPPHASE = 3 };  // 2: the ring schedule's half mode (odd number of half chunks)
+                                                                                       // 3: four 2x2 phase kernels of an upsampling layer (conv_ring_up.h)
 
 // A descriptor takes the ring schedule (conv_ring.h) iff: 3x3, three products, split-plane / f32-map outputs (final NCHW stores: the
 // three-tile shape only) and either whole
@@ -31,11 +32,25 @@ inline bool conv_ring_eligible(const rsa_conv_params& p) {
   if ((p.cin_planes & 3) == 0) return ct == 2 || ct == 4 || (ct == 3 && !p.upsample2x);
   return ct == 3 && !p.upsample2x;
 }
-inline int conv_ring_layout(const rsa_conv_params& p) { return (p.cin_planes & 3) == 0 ? RSA_WL_PAIRS : RSA_WL_HALFPAIRS; }
+// Nearest x2 upsampling + 3x3 as four 2x2 phase convolutions on the source map (conv_ring_up.h): 64 -> 64 channels, LeakyReLU / none,
+// split-plane output only -- the upconv layers of RRDBNet and of SwinIR's nearest+conv head.  RSA_CONV_UP2=0 switches it off (A/B runs).
+bool conv_up2_enabled();
+inline bool conv_ring_up2_eligible(const rsa_conv_params& p) {
+  return p.ksize == 3 && p.products == 3 && p.upsample2x && p.cin_planes == 8 && p.cout == 64 && !(p.H & 1) && !(p.W & 1) && p.out_hi != nullptr &&
+         p.out_lo != nullptr && p.out_f32 == nullptr && p.out_nchw == nullptr && p.res1 == nullptr && p.res2 == nullptr && p.res1_hi == nullptr &&
+         p.res2_hi == nullptr && (p.act == RSA_ACT_NONE || (p.act == RSA_ACT_LRELU && p.act_param >= 0.f && p.act_param <= 1.f));
+}
+inline int conv_ring_layout(const rsa_conv_params& p) {
+  if (conv_up2_enabled() && conv_ring_up2_eligible(p)) return RSA_WL_UPPHASE;
+  return (p.cin_planes & 3) == 0 ? RSA_WL_PAIRS : RSA_WL_HALFPAIRS;
+}
 inline int conv_weight_layout(const rsa_conv_params& p) { return (conv_ring_enabled() && conv_ring_eligible(p)) ? conv_ring_layout(p) : RSA_WL_TAPS; }
 
 // conv_inst_ring*.hip
 int conv_launch_ring(const rsa_conv_params& p, hipStream_t stream);
+int conv_launch_ring_up2(const rsa_conv_params& p, hipStream_t stream);
+// bytes of a packed blob in a given layout (layout 3 is larger than the chunked ones: 32 K steps per 64 x 64 layer)
+int64_t packed_weight_bytes(int cout, int cin_planes, int ksize, int products, int layout);
 unsigned int conv_ring_aborts();
 
 }  // namespace rsa

@@ -106,6 +106,25 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
   lo = __builtin_bit_cast(uint32_t, l);
 }
 
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+// Two D fragments of the pixel-tile pair (2k, 2k+1) of one 16-channel tile -> the 16-byte plane units of plane 2*ct + (lg >> 1):
+// the even lane group ends up with the full unit of token tile 2k, the odd one with that of 2k+1 (v_permlane16_swap, as the
+// convolution epilogue).  Returns the token tile this lane stores.
+__device__ __forceinline__ void pair_units(const f32x4 a, const f32x4 b, uint4& uh, uint4& ul) {
+  uint32_t h[2][2], l[2][2];
+  split2(a[0], a[1], h[0][0], l[0][0]);
+  split2(a[2], a[3], h[0][1], l[0][1]);
+  split2(b[0], b[1], h[1][0], l[1][0]);
+  split2(b[2], b[3], h[1][1], l[1][1]);
+  const u32x2 h0 = __builtin_amdgcn_permlane16_swap(h[0][0], h[1][0], false, false);
+  const u32x2 h1 = __builtin_amdgcn_permlane16_swap(h[0][1], h[1][1], false, false);
+  const u32x2 l0 = __builtin_amdgcn_permlane16_swap(l[0][0], l[1][0], false, false);
+  const u32x2 l1 = __builtin_amdgcn_permlane16_swap(l[0][1], l[1][1], false, false);
+  uh = make_uint4(h0.x, h1.x, h0.y, h1.y);
+  ul = make_uint4(l0.x, l1.x, l0.y, l1.y);
+}
+
 // Geometry of one instantiation.  Output tile = 16 rows x 32 pixels.  A COMPUTE wave owns NPT pixel-tiles (RPW rows x 2 halves of
 // 16 pixels) x CTW cout-tiles; one tap costs it 2*NPT LDS fragment reads + 2*CTW weight fragment loads for 3*NPT*CTW MFMAs.
 //   NCT == 3 : 8 compute waves = 8 row-groups of 2 rows, every wave owns ALL 3 cout tiles of 4 pixel-tiles (no padded cout slot:
@@ -335,7 +354,6 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
           // 2k and b = its half of 2k+1, an even lane ends up with (own half of 2k, partner's half of 2k) and an odd lane with
           // (partner's half of 2k+1, own half of 2k+1) -- the full 16-byte units, one instruction per register pair, no selects
 #ifndef RSA_EPI_SHFL
-          typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
           const u32x2 h0 = __builtin_amdgcn_permlane16_swap(h[0][0], h[1][0], false, false);
           const u32x2 h1 = __builtin_amdgcn_permlane16_swap(h[0][1], h[1][1], false, false);
           const u32x2 l0 = __builtin_amdgcn_permlane16_swap(l[0][0], l[1][0], false, false);

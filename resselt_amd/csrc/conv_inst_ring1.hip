@@ -5,18 +5,19 @@ namespace rsa {
 int conv_launch_ring2(const rsa_conv_params& p, hipStream_t stream);  // conv_inst_ring2.hip
 int conv_launch_ring3(const rsa_conv_params& p, hipStream_t stream);  // conv_inst_ring3.hip
 
+unsigned int conv_ring2_aborts();     // conv_inst_ring2.hip
+unsigned int conv_ring3_aborts();     // conv_inst_ring3.hip
+unsigned int conv_ring_up2_aborts();  // conv_inst_ringup.hip
+
 int conv_launch_ring(const rsa_conv_params& p, hipStream_t stream) {
+  if (p.w_layout == RSA_WL_UPPHASE) return conv_launch_ring_up2(p, stream);
   const int ct = (p.cout + 15) >> 4;
   if (ct == 2) return conv_launch_ring2(p, stream);
   if (ct == 3) return conv_launch_ring3(p, stream);
   return p.upsample2x ? launch_ring<1, 1, 0>(p, stream) : launch_ring<1, 0, 0>(p, stream);
 }
 
-unsigned int conv_ring_aborts() {
-  unsigned int v = 0;
-  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ring_aborts), sizeof(v)) != hipSuccess) return 0xFFFFFFFFu;
-  return v;
-}
+unsigned int conv_ring_aborts() { return ring_aborts_this_unit() + conv_ring2_aborts() + conv_ring3_aborts() + conv_ring_up2_aborts(); }
 }  // namespace rsa
 
 #ifdef RSA_RING_DEBUG

@@ -5,6 +5,7 @@ namespace rsa {
 int conv_launch_ring2(const rsa_conv_params& p, hipStream_t stream) {
   return p.upsample2x ? launch_ring<2, 1, 0>(p, stream) : launch_ring<2, 0, 0>(p, stream);
 }
+unsigned int conv_ring2_aborts() { return ring_aborts_this_unit(); }
 #ifdef RSA_RING_DEBUG
 int conv_ring2_set_dbg(unsigned v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_ring_dbg), &v, sizeof(v)) == hipSuccess ? 0 : -1; }
 #endif

@@ -21,6 +21,13 @@ int conv_launch_k1p1(const rsa_conv_params& p, int nct, hipStream_t stream);
 
 static std::atomic<int> g_ring_override{-1};  // rsa_debug_set_ring: -1 = follow the environment, 0 / 1 = forced (in-process A/B runs)
 void conv_ring_override(int v) { g_ring_override.store(v < 0 ? -1 : (v ? 1 : 0)); }
+bool conv_up2_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("RSA_CONV_UP2");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  return on;
+}
 bool conv_ring_enabled() {
   static const bool on = [] {
     const char* e = getenv("RSA_CONV_RING");
@@ -32,6 +39,7 @@ bool conv_ring_enabled() {
 
 // Name of the kernel a descriptor dispatches to (bench.py groups its per-kernel roofline by it; matches the rocprofv3 kernel names).
 const char* conv_kernel_name(const rsa_conv_params& p) {
+  if (p.w_layout == RSA_WL_UPPHASE) return "rsa::conv_ring_up2 (x2 upsampling as four 2x2 phases)";
   if (p.w_layout != RSA_WL_TAPS) {
     const int ct = (p.cout + 15) >> 4;
     return ct == 2 ? "rsa::conv_ring<2,UP,0> (Cout<=32)" : ct == 3 ? (p.out_nchw != nullptr ? "rsa::conv_ring<3,0,1,HM> (Cout 33..48, final store)" : "rsa::conv_ring<3,0,0,HM> (Cout 33..48)") : "rsa::conv_ring<1,UP,0> (Cout 49..64)";
@@ -83,10 +91,12 @@ int conv_launch(const rsa_conv_params& p, hipStream_t stream) {
     if (p.out_dtype < RSA_F32 || p.out_dtype > RSA_U8) return set_error(RSA_E_ARG, "conv: bad out_dtype");
     if (p.out_dtype == RSA_U8 && p.out_base != nullptr) return set_error(RSA_E_UNSUPPORTED, "conv: an 8-bit image store takes no base image");
   }
-  if (p.w_layout < RSA_WL_TAPS || p.w_layout > RSA_WL_HALFPAIRS) return set_error(RSA_E_ARG, "conv: unknown w_layout");
+  if (p.w_layout < RSA_WL_TAPS || p.w_layout > RSA_WL_UPPHASE) return set_error(RSA_E_ARG, "conv: unknown w_layout");
   if (p.w_layout != RSA_WL_TAPS) {  // ring schedule (conv_ring.h): the descriptor carries the K order its weights were packed in
-    if (!conv_ring_eligible(p) || p.w_layout != conv_ring_layout(p))
-      return set_error(RSA_E_ARG, "conv: w_layout 1 / 2 (tap pairs) on a descriptor the ring schedule does not take that way (ask rsa_conv_weight_layout)");
+    // (layout 3 stays valid when RSA_CONV_UP2 / the debug override change what rsa_conv_weight_layout would answer now)
+    const bool ok = p.w_layout == RSA_WL_UPPHASE ? conv_ring_up2_eligible(p)
+                                                 : conv_ring_eligible(p) && p.w_layout == ((p.cin_planes & 3) == 0 ? RSA_WL_PAIRS : RSA_WL_HALFPAIRS);
+    if (!ok) return set_error(RSA_E_ARG, "conv: w_layout 1 / 2 / 3 on a descriptor the ring schedule does not take that way (ask rsa_conv_weight_layout)");
     if (p.in_plane_stride * 32 >= (int64_t)1 << 32) return set_error(RSA_E_UNSUPPORTED, "conv: input plane too large for 32-bit lane offsets; band the image");
     const int rc = conv_launch_ring(p, stream);
     return rc ? set_error(rc, "conv: ring kernel launch failed") : RSA_OK;

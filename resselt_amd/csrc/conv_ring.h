@@ -49,6 +49,12 @@ static __device__ unsigned int g_ring_dbg;
 #endif
 
 static __device__ unsigned int g_ring_aborts;  // spins that ran into RSA_RING_SPIN_LIMIT (a protocol bug): never non-zero in a correct build
+// (one counter per translation unit that instantiates the schedule; conv_ring_aborts() adds them up)
+static unsigned int ring_aborts_this_unit() {
+  unsigned int v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ring_aborts), sizeof(v)) != hipSuccess) return 0x10000000u;
+  return v;
+}
 
 typedef const __attribute__((address_space(1))) char* gcptr;
 

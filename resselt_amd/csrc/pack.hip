@@ -11,6 +11,10 @@
 //        s = 5,6,7: half B, tap (dy = s-5, dx = h)    s = 8: half B, tap (dy = h, dx = 2)
 //   layout RSA_WL_HALFPAIRS (conv_ring.h half mode, an odd number of half chunks): blob[half][s][ct][hl][lane][j], s = 0..4, plane
 //        2*half + (lg & 1):  s = 0,1,2: tap (dy = s, dx = h)   s = 3: tap (dy = h, dx = 2)   s = 4: tap (2,2) for h = 0, ZERO for h = 1
+//   layout RSA_WL_UPPHASE (conv_ring_up.h: nearest x2 upsampling + 3x3 as four 2x2 convolutions on the source map, 64 -> 64 channels):
+//        blob[phase][half][s][ct][hl][lane][j], phase = 2*py + px (output pixel parity), half = 16-channel half chunk 0..3, s = source row
+//        0..1, plane 2*half + (lg & 1), source column h = lg >> 1.  The weight of source pixel (s, h) is the SUM (in f32) of the 3x3 taps
+//        that read it on the upsampled image: rows {0} / {1,2} for py = 0, {0,1} / {2} for py = 1, columns likewise with px.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -88,14 +92,64 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int cout, int c
   }
 }
 
+__global__ void pack_weights_upphase_kernel(const float* __restrict__ w, int cout, int cin, void* out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (K step t 0..31, cout tile 0..3, lane)
+  if (idx >= 32 * 4 * 64) return;
+  const int lane = idx & 63, ct = (idx >> 6) & 3, t = idx >> 8;
+  const int phase = t >> 3, half = (t >> 1) & 3, s = t & 1;
+  const int py = phase >> 1, px = phase & 1;
+  const int lg = lane >> 4, h = lg >> 1;
+  const int co = 16 * ct + (lane & 15);
+  const int plane = 2 * half + (lg & 1);
+  // taps (of the 3x3 kernel on the upsampled image) that read source row s / source column h of this phase
+  const int ky0 = py == 0 ? (s == 0 ? 0 : 1) : (s == 0 ? 0 : 2), ky1 = py == 0 ? (s == 0 ? 0 : 2) : (s == 0 ? 1 : 2);
+  const int kx0 = px == 0 ? (h == 0 ? 0 : 1) : (h == 0 ? 0 : 2), kx1 = px == 0 ? (h == 0 ? 0 : 2) : (h == 0 ? 1 : 2);
+  pk_bf16x8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ci = 8 * plane + j;
+    float v = 0.f;
+    if (co < cout && ci < cin)
+      for (int ky = ky0; ky <= ky1; ++ky)
+        for (int kx = kx0; kx <= kx1; ++kx) v += w[(((int64_t)co * cin + ci) * 3 + ky) * 3 + kx];
+    const __bf16 hb = (__bf16)v;
+    hi[j] = hb;
+    lo[j] = (__bf16)(v - (float)hb);
+  }
+  const int64_t frag = ((int64_t)t * 4 + ct) * 2;
+  ((pk_bf16x8*)out)[frag * 64 + lane] = hi;
+  ((pk_bf16x8*)out)[(frag + 1) * 64 + lane] = lo;
+}
+
+int64_t packed_weight_bytes(int cout, int cin_planes, int ksize, int products, int layout) {
+  if (cout < 1 || cin_planes < 1 || (ksize != 1 && ksize != 3) || (products != 1 && products != 3)) return RSA_E_ARG;
+  if (layout == RSA_WL_UPPHASE) return (cout == 64 && cin_planes == 8 && ksize == 3 && products == 3) ? (int64_t)32 * 4 * 2 * 64 * 16 : (int64_t)RSA_E_UNSUPPORTED;
+  if (layout < RSA_WL_TAPS || layout > RSA_WL_UPPHASE) return RSA_E_ARG;
+  const int64_t ct = (cout + 15) / 16;
+  const int64_t chunks = (cin_planes + 3) / 4;
+  const int64_t nhl = products == 3 ? 2 : 1;
+  return chunks * ksize * ksize * ct * nhl * 64 * 16;
+}
+
 }  // namespace rsa
+
+extern "C" int64_t rsa_packed_weight_bytes_layout(int32_t cout, int32_t cin_planes, int32_t ksize, int32_t products, int32_t layout) {
+  return rsa::packed_weight_bytes(cout, cin_planes, ksize, products, layout);
+}
 
 extern "C" int rsa_pack_weights(const float* w_oihw, int32_t cout, int32_t cin, int32_t cin_planes, int32_t ksize, int32_t products, int32_t layout,
                                 void* out, void* stream) {
   if (w_oihw == nullptr || out == nullptr || cout < 1 || cin < 1 || cin_planes < 1) return rsa::set_error(RSA_E_ARG, "pack_weights: bad argument");
   if ((ksize != 1 && ksize != 3) || (products != 1 && products != 3)) return rsa::set_error(RSA_E_ARG, "pack_weights: ksize must be 1 or 3, products 1 or 3");
   if (cin > 8 * cin_planes) return rsa::set_error(RSA_E_ARG, "pack_weights: cin does not fit in cin_planes");
-  if (layout < rsa::RSA_WL_TAPS || layout > rsa::RSA_WL_HALFPAIRS) return rsa::set_error(RSA_E_ARG, "pack_weights: unknown layout");
+  if (layout < rsa::RSA_WL_TAPS || layout > rsa::RSA_WL_UPPHASE) return rsa::set_error(RSA_E_ARG, "pack_weights: unknown layout");
+  if (layout == rsa::RSA_WL_UPPHASE) {
+    if (ksize != 3 || products != 3 || cin_planes != 8 || cout != 64) return rsa::set_error(RSA_E_UNSUPPORTED, "pack_weights: the upsampling-phase layout is for 3x3, 3-product, 64 -> 64 channel layers");
+    if ((uintptr_t)out & 15) return rsa::set_error(RSA_E_ALIGN, "pack_weights: out must be 16-byte aligned");
+    hipLaunchKernelGGL(rsa::pack_weights_upphase_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, out);
+    const int rcu = (int)hipGetLastError();
+    return rcu ? rsa::set_error(rcu, "pack_weights: launch failed") : RSA_OK;
+  }
   if (layout == rsa::RSA_WL_PAIRS && (ksize != 3 || products != 3 || (cin_planes & 3))) return rsa::set_error(RSA_E_UNSUPPORTED, "pack_weights: the tap-pair layout needs a 3x3, 3-product layer with whole 32-channel chunks");
   if (layout == rsa::RSA_WL_HALFPAIRS && (ksize != 3 || products != 3 || (cin_planes & 1))) return rsa::set_error(RSA_E_UNSUPPORTED, "pack_weights: the half-chunk tap-pair layout needs a 3x3, 3-product layer with an even number of input planes");
   if ((uintptr_t)out & 15) return rsa::set_error(RSA_E_ALIGN, "pack_weights: out must be 16-byte aligned");

@@ -5,7 +5,6 @@
 
 namespace rsa {
 
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 constexpr int SB_TOK = 64;  // tokens per workgroup
 constexpr float LOG2E = 1.44269504088896340736f;
@@ -226,23 +225,6 @@ __device__ __forceinline__ f32x4 mfma3(const bf16x8 ah, const bf16x8 al, const b
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
   }
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
-}
-
-// Two D fragments of the token-tile pair (2k, 2k+1) of one 16-channel tile -> the 16-byte plane units of plane 2*ct + (lg >> 1):
-// the even lane group ends up with the full unit of token tile 2k, the odd one with that of 2k+1 (v_permlane16_swap, as the
-// convolution epilogue).  Returns the token tile this lane stores.
-__device__ __forceinline__ void pair_units(const f32x4 a, const f32x4 b, uint4& uh, uint4& ul) {
-  uint32_t h[2][2], l[2][2];
-  split2(a[0], a[1], h[0][0], l[0][0]);
-  split2(a[2], a[3], h[0][1], l[0][1]);
-  split2(b[0], b[1], h[1][0], l[1][0]);
-  split2(b[2], b[3], h[1][1], l[1][1]);
-  const u32x2 h0 = __builtin_amdgcn_permlane16_swap(h[0][0], h[1][0], false, false);
-  const u32x2 h1 = __builtin_amdgcn_permlane16_swap(h[0][1], h[1][1], false, false);
-  const u32x2 l0 = __builtin_amdgcn_permlane16_swap(l[0][0], l[1][0], false, false);
-  const u32x2 l1 = __builtin_amdgcn_permlane16_swap(l[0][1], l[1][1], false, false);
-  uh = make_uint4(h0.x, h1.x, h0.y, h1.y);
-  ul = make_uint4(l0.x, l1.x, l0.y, l1.y);
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const void* w, int64_t bytes) {

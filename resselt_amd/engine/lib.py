@@ -393,6 +393,7 @@ EXPORTS = (
     'rsa_conv2d_list',
     'rsa_conv_cout_tiles',
     'rsa_packed_weight_bytes',
+    'rsa_packed_weight_bytes_layout',
     'rsa_conv_weight_layout',
     'rsa_pack_weights',
     'rsa_conv_kernel_name',
@@ -471,6 +472,8 @@ def load() -> C.CDLL:
     lib.rsa_conv_cout_tiles.restype = C.c_int
     lib.rsa_packed_weight_bytes.argtypes = [C.c_int32] * 4
     lib.rsa_packed_weight_bytes.restype = C.c_int64
+    lib.rsa_packed_weight_bytes_layout.argtypes = [C.c_int32] * 5
+    lib.rsa_packed_weight_bytes_layout.restype = C.c_int64
     lib.rsa_conv_weight_layout.argtypes = [C.POINTER(ConvParams)]
     lib.rsa_conv_weight_layout.restype = C.c_int
     lib.rsa_pack_weights.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]

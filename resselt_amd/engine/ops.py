@@ -40,7 +40,7 @@ def pack_weights_device(w: torch.Tensor, cin_planes: int, products: int, layout:
     w = w.to(torch.float32).contiguous()
     cout, cin, k, _ = w.shape
     lib = L.load()
-    nbytes = int(lib.rsa_packed_weight_bytes(cout, cin_planes, k, products))
+    nbytes = int(lib.rsa_packed_weight_bytes_layout(cout, cin_planes, k, products, layout))
     if nbytes <= 0:
         raise ValueError(f'unsupported convolution shape cout={cout} cin_planes={cin_planes} k={k} products={products}')
     out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)

@@ -122,6 +122,33 @@ def pack_conv_weights_halfpairs(w: torch.Tensor, cin_planes: int) -> torch.Tenso
     return full
 
 
+def pack_conv_weights_upphase(w: torch.Tensor) -> torch.Tensor:
+    """Layout 3 (csrc/conv_ring_up.h: nearest x2 upsampling + 3x3 as four 2x2 convolutions on the source map, 64 -> 64 channels):
+    packed[phase][half][s][ct][hl][lane][j]; phase = 2*py + px (output pixel parity), lane group lg reads plane 2*half + (lg & 1) at
+    source row s, source column h = lg >> 1; its weight is the f32 SUM of the 3x3 taps that read that source pixel on the upsampled
+    image: rows {0} / {1, 2} for py = 0, {0, 1} / {2} for py = 1; columns likewise."""
+    cout, cin, k, _ = w.shape
+    if (cout, cin, k) != (64, 64, 3):
+        raise ValueError('the upsampling-phase layout is for 64 -> 64 channel 3x3 layers')
+    taps = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}  # parity -> source index -> taps
+    w = w.to(torch.float32)
+    out = torch.zeros((4, 4, 2, 4, 2, 64, 8), dtype=torch.bfloat16, device=w.device)
+    for py in range(2):
+        for px in range(2):
+            for s in range(2):
+                for lg in range(4):
+                    h = lg >> 1
+                    summed = torch.zeros((cout, cin), dtype=torch.float32, device=w.device)
+                    for ky in taps[py][s]:  # (the kernel adds in the same order: ky outer, kx inner)
+                        for kx in taps[px][h]:
+                            summed = summed + w[:, :, ky, kx]
+                    hi, lo = split_bf16(summed)
+                    for hl, src in enumerate((hi, lo)):
+                        v = src.reshape(4, 16, 4, 2, 8)[:, :, :, lg & 1, :].permute(2, 0, 1, 3)  # [half, ct, 16 lanes, 8]
+                        out[2 * py + px, :, s, :, hl, lg * 16 : lg * 16 + 16, :] = v
+    return out.reshape(-1)
+
+
 def pad_bias(b: torch.Tensor | None, cout: int, device) -> torch.Tensor:
     """f32 bias padded to a multiple of 16 (zeros) so the kernel may read whole tiles."""
     out = torch.zeros(((cout + 15) // 16) * 16, dtype=torch.float32, device=device)

@@ -209,7 +209,7 @@ def test_argument_errors(device):
         ops.run_convs([p], device)
 
 
-@pytest.mark.parametrize('layout', [0, 1, 2])
+@pytest.mark.parametrize('layout', [0, 1, 2, 3])
 def test_pack_weights_kernel_matches_torch_packers(device, layout):
     """rsa_pack_weights (csrc/pack.hip) against the torch restatement of the three blob layouts (engine/pack.py)."""
     from resselt_amd.engine import pack
@@ -218,8 +218,9 @@ def test_pack_weights_kernel_matches_torch_packers(device, layout):
         0: [(27, 61, 8, 3, 3), (64, 192, 24, 3, 3), (3, 64, 8, 3, 1), (720, 240, 30, 1, 3), (20, 11, 2, 3, 3)],
         1: [(27, 61, 8, 3, 3), (64, 192, 24, 3, 3)],
         2: [(48, 48, 6, 3, 3), (43, 77, 10, 3, 3), (20, 11, 2, 3, 3)],
+        3: [(64, 64, 8, 3, 3)],
     }[layout]
-    ref = {0: lambda w, pl, pr: pack.pack_conv_weights(w, pl, pr), 1: lambda w, pl, pr: pack.pack_conv_weights_pairs(w, pl), 2: lambda w, pl, pr: pack.pack_conv_weights_halfpairs(w, pl)}[layout]
+    ref = {0: lambda w, pl, pr: pack.pack_conv_weights(w, pl, pr), 1: lambda w, pl, pr: pack.pack_conv_weights_pairs(w, pl), 2: lambda w, pl, pr: pack.pack_conv_weights_halfpairs(w, pl), 3: lambda w, pl, pr: pack.pack_conv_weights_upphase(w)}[layout]
     for cout, cin, planes, k, products in cases:
         w = _rand((cout, cin, k, k), cout + cin)
         got = ops.pack_weights_device(w.to(device), planes, products, layout).cpu()
@@ -319,3 +320,34 @@ def test_conv_rdb_epilogue_plane_residuals(device, ring):
     got = tensors.planes_to_nchw(tensors.Planes(dst.hi[:, :8].contiguous(), dst.lo[:, :8].contiguous()), 64)
     assert (got.cpu() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
     assert L.ring_aborts() == 0
+
+
+@pytest.mark.parametrize('n,h,w', [(1, 360, 520), (2, 66, 130), (1, 34, 70), (1, 2, 2)])
+def test_conv_upsample_as_four_phase_kernels(device, n, h, w):
+    """nearest x2 + 3x3 + LeakyReLU, 64 -> 64, split-plane output: csrc/conv_ring_up.h (four 2x2 convolutions on the source map, weight
+    layout 3) against torch on the upsampled image, over the whole map (ragged source tiles, every border), and against the schedule that
+    multiplies all nine taps on the upsampled halo tile (RSA_CONV_UP2 is read once per process, so that one runs through an f32 output)."""
+    x = _rand((n, 64, h // 2, w // 2), 51)
+    wt = _rand((64, 64, 3, 3), 52, 1.0 / (64 * 9) ** 0.5)
+    b = _rand((64,), 53, 0.1)
+    ref = F.leaky_relu(_ref_conv(x, wt, b, up=True), 0.2)
+    wts = ops.ConvWeights.from_oihw(wt, b, 3, device=device)
+    xin = tensors.nchw_to_planes(x.to(device))
+    out = tensors.Planes.empty(n, 8, h, w, device)
+    out.hi.fill_(float('nan'))
+    p = ops.conv_params(wts, xin, h, w, upsample2x=True, out=out, act=L.ACT_LRELU, act_param=0.2)
+    assert p.w_layout == 3 and 'conv_ring_up2' in L.conv_kernel_name(p)
+    before = L.ring_aborts()
+    ops.run_convs([p], device)
+    torch.cuda.synchronize()
+    assert L.ring_aborts() == before == 0
+    got = tensors.planes_to_nchw(out, 64).cpu()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    of32 = tensors.empty_f32map(n, 64, h, w, device)
+    out2 = tensors.Planes.empty(n, 8, h, w, device)
+    p2 = ops.conv_params(wts, xin, h, w, upsample2x=True, out=out2, out_f32=of32, act=L.ACT_LRELU, act_param=0.2)  # f32 output: the nine-tap schedule
+    assert p2.w_layout == 1
+    ops.run_convs([p2], device)
+    torch.cuda.synchronize()
+    assert (tensors.planes_to_nchw(out2, 64).cpu() - got).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())

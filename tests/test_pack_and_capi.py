@@ -154,3 +154,37 @@ def test_halfpair_layout_matches_index_formula():
     assert len(seen) == 18 and set(seen) == {(pl, ky, kx) for pl in range(2) for ky in range(3) for kx in range(3)}
     with pytest.raises(ValueError):
         pack.pack_conv_weights_pairs(w, planes)  # whole chunks only
+
+
+def test_upphase_layout_is_the_upsampled_convolution():
+    """Layout 3: the four 2x2 phase kernels (taps pre-summed) reproduce nearest x2 upsampling + 3x3 convolution exactly in f32, and the
+    packed fragments hold those sums in the documented order."""
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(9)
+    w = torch.randn((64, 64, 3, 3), generator=g) * 0.05
+    x = torch.randn((1, 64, 5, 7), generator=g)
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode='nearest'), w.double(), padding=1)
+    taps = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+    out = torch.zeros_like(ref)
+    xp = F.pad(x.double(), (1, 1, 1, 1))
+    for py in range(2):
+        for px in range(2):
+            k2 = torch.zeros((64, 64, 2, 2), dtype=torch.float64)
+            for s in range(2):
+                for h in range(2):
+                    for ky in taps[py][s]:
+                        for kx in taps[px][h]:
+                            k2[:, :, s, h] += w[:, :, ky, kx].double()
+            # source rows y - 1 + py + s  ->  on the padded map rows y + py + s
+            out[:, :, py::2, px::2] = F.conv2d(xp[:, :, py : py + 6, px : px + 8], k2)
+    assert (out - ref).abs().max().item() <= 1e-12
+    blob = pack.pack_conv_weights_upphase(w).reshape(4, 4, 2, 4, 2, 64, 8)
+    for phase, half, s, ct, lane, j in [(0, 0, 0, 0, 0, 0), (1, 2, 1, 3, 37, 5), (2, 3, 0, 1, 63, 7), (3, 1, 1, 2, 20, 3)]:
+        lg, li = lane >> 4, lane & 15
+        py, px, h = phase >> 1, phase & 1, lg >> 1
+        co, ci = 16 * ct + li, 16 * half + 8 * (lg & 1) + j
+        want = sum(w[co, ci, ky, kx] for ky in taps[py][s] for kx in taps[px][h])
+        hi = _bf16(torch.tensor(float(want)))
+        assert blob[phase, half, s, ct, 0, lane, j].item() == hi.item()
+        assert blob[phase, half, s, ct, 1, lane, j].item() == _bf16(torch.tensor(float(want)) - hi.float()).item()

@@ -19,6 +19,9 @@ from resselt_amd.engine import lib as L  # noqa: E402
 from resselt_amd.engine import ops, tensors  # noqa: E402
 
 dev = torch.device('cuda:0')
+if os.environ.get('RSA_LIB'):
+    _p = os.path.abspath(os.environ['RSA_LIB'])
+    L.lib_path = lambda: _p  # an experiment build (tools/variant.sh)
 lib = L.load()
 configs = [(64, 32), (96, 32), (128, 32), (160, 32), (192, 64), (64, 64)]
 if len(sys.argv) > 1:
