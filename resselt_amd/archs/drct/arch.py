@@ -187,13 +187,20 @@ class DRCT(EngineModule):
         W['mean'] = torch.tensor(RGB_MEAN if self.in_chans == 3 else [0.0] * self.in_chans, dtype=torch.float32, device=device)
         return W
 
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """A batch runs image by image through the one-image plan (the dense concatenation of a group is addressed by channel-group
+        offsets inside ONE image's token map); the reference's `forward` (archs/drct/arch.py:756-792) is per-image arithmetic throughout."""
+        if x.dim() == 4 and x.shape[0] > 1:
+            return torch.cat([super(DRCT, self).forward(x[i : i + 1]) for i in range(x.shape[0])], 0)
+        return super().forward(x)
+
     # ---------------------------------------------------------------- plan
     def _build_plan(self, plan: Plan, W, x_shape, dtype, products):
         n, c, h0, w0 = x_shape
         if c != self.in_chans:
             raise RuntimeError(f'model expects {self.in_chans} input channels, got {c}')
         if n != 1:
-            raise NotImplementedError('the DRCT engine runs one image per call (the dense concatenation is addressed by channel-group offsets)')
+            raise NotImplementedError('a DRCT plan holds one image (forward() splits batches)')
         win = self.window_size
         H, Wd = h0 + (win - h0 % win) % win, w0 + (win - w0 % win) % win
         if H - h0 >= h0 or Wd - w0 >= w0:
