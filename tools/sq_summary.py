@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise two rocprofv3 --pmc passes (SQ counters; GRBM_GUI_ACTIVE) per conv kernel family: clock and MFMA busy %.
+"""Summarise two rocprofv3 --pmc passes (SQ counters; GRBM_GUI_ACTIVE) per conv / Swin-block kernel family: clock and MFMA busy %.
 
 usage: sq_summary.py PASS1.db PASS2.db OUT.txt
 """
@@ -13,10 +13,10 @@ def agg(db):
     out = collections.defaultdict(lambda: collections.defaultdict(float))
     n, dur = collections.Counter(), collections.defaultdict(float)
     for k, c, v in con.execute('select kernel_name, counter_name, value from counters_collection'):
-        if 'conv_' in k:
+        if 'conv_' in k or 'swin_' in k:
             out[k.split('(')[0].replace('void rsa::', '')][c] += v
     for k, d in con.execute('select name, duration from kernels'):
-        if 'conv_' in k:
+        if 'conv_' in k or 'swin_' in k:
             fam = k.split('(')[0].replace('void rsa::', '')
             n[fam] += 1
             dur[fam] += d
