@@ -57,6 +57,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-crop', type=int, default=256)
     ap.add_argument('--halo', type=int, default=32)
+    ap.add_argument('--no-power', action='store_true', help='skip the socket-power leg (rocm-smi sampled by a child process started before the GPU is touched)')
     ap.add_argument('--no-kernel-roofline', action='store_true', help='skip the per-kernel replays (profiling runs: keeps the launch mix that of plain forwards)')
     ap.add_argument('--dry-run', action='store_true', help='launcher / rendezvous check without a GPU: ranks meet over gloo, rank 0 prints a stub line')
     ap.add_argument('--config', default='c2', choices=['c2', 'c5'], help='c2: N tiles of 1080p (weak scaling); c5: one 4320x7680 input, 2x4 tiles (strong scaling)')
@@ -213,6 +214,67 @@ def dry_run(args, world: int, rank: int) -> None:
                           'config': {'workload': args.config}}), flush=True)  # fmt: skip
 
 
+_SAMPLER = r"""
+import re, subprocess, sys, time
+out = open(sys.argv[1], 'w', buffering=1)
+while True:
+    try:
+        txt = subprocess.run(['rocm-smi', '--showpower', '--showclocks', '--showmaxpower'], capture_output=True, text=True, timeout=10).stdout
+    except Exception:
+        break
+    t = time.time()
+    pw = [float(v) for v in re.findall(r'Current Socket Graphics Package Power \(W\): ([\d.]+)', txt)]
+    ck = [float(v) for v in re.findall(r'sclk clock level: \S+ \((\d+)Mhz\)', txt)]
+    cap = [float(v) for v in re.findall(r'Max Graphics Package Power \(W\): ([\d.]+)', txt)]
+    if pw:
+        i = max(range(len(pw)), key=lambda k: pw[k])  # the busy GPU of the node
+        out.write(f'{t} {pw[i]} {ck[i] if i < len(ck) else 0} {cap[i] if i < len(cap) else 0}\n')
+"""
+
+
+class PowerSampler:
+    """Socket power / shader clock of the busiest GPU, sampled by a CHILD process (python + rocm-smi, ~5 samples per second) that is
+    started before this process touches the GPU and never touches it itself; the samples are matched to the power leg by wall clock."""
+
+    def __init__(self):
+        import shutil
+        import subprocess
+        import tempfile
+
+        self.proc, self.path = None, None
+        if shutil.which('rocm-smi') is None:
+            return
+        fd, self.path = tempfile.mkstemp(prefix='rsa_power_', suffix='.txt')
+        os.close(fd)
+        self.proc = subprocess.Popen([sys.executable, '-c', _SAMPLER, self.path], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        import atexit
+
+        atexit.register(lambda p=self.proc: p.poll() is None and p.terminate())  # never outlives the bench
+
+    def stop(self, t0: float, t1: float):
+        if self.proc is None:
+            return None
+        self.proc.terminate()
+        try:
+            self.proc.wait(timeout=15)
+        except Exception:
+            self.proc.kill()
+        rows = []
+        try:
+            for line in open(self.path):
+                v = line.split()
+                if len(v) == 4 and t0 <= float(v[0]) <= t1:
+                    rows.append([float(a) for a in v])
+            os.unlink(self.path)
+        except OSError:
+            return None
+        if not rows:
+            return None
+        pw, ck = [r[1] for r in rows], [r[2] for r in rows]
+        return {'avg_w': round(sum(pw) / len(pw), 1), 'max_w': max(pw), 'cap_w': rows[-1][3] or None, 'sclk_mhz_avg': round(sum(ck) / len(ck)),
+                'samples': len(rows), 'note': 'rocm-smi socket power of the busiest GPU over the last 2 s of a 3.5 s run of back-to-back forwards (sensor averaging window ~1 s)'}  # fmt: skip
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -228,6 +290,7 @@ def main():
         raise SystemExit('--config c5 has 8 tiles: --gpus must divide 8')
     if args.dry_run:
         return dry_run(args, world, rank)
+    sampler = PowerSampler() if (world == 1 and not args.no_power) else None  # (a child process: started before the first GPU call)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the engine has no CPU path')
     # RSA_DIST_BACKEND=gloo rehearses the N > 1 code path with several ranks on ONE GPU (RCCL refuses two ranks per device)
@@ -403,6 +466,13 @@ def main():
             'event_ms_per_step': round(ev_ms / args.steps, 3),
             'forward_ms_1080p': round(kern_s * 1e3, 3),
         }
+        if sampler is not None:  # power leg: 3.5 s of back-to-back forwards, the last 2 s of samples
+            w0 = time.time()
+            while time.time() - w0 < 3.5:
+                model(xt)
+                torch.cuda.synchronize()
+            w1 = time.time()
+            res['power'] = sampler.stop(w1 - 2.0, w1)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(sd, args.cpu_crop)
         print(json.dumps(res), flush=True)
