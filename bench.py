@@ -144,7 +144,10 @@ def measured_traffic() -> dict:
         return {'bytes': None, 'note': 'no PMC summary under profiles/'}
     rec = json.load(open(files[-1]))
     name = os.path.basename(files[-1])
-    have = open(B.STAMP).read().strip() if os.path.exists(B.STAMP) else None
+    have = None
+    if os.path.exists(B.STAMP):
+        with open(B.STAMP) as f:
+            have = f.read().strip()
     if rec.get('srchash') is None or rec.get('srchash') != have:
         return {'bytes': None, 'note': f'{name} was collected on another build (srchash {str(rec.get("srchash"))[:12]} != loaded {str(have)[:12]}): stale, not reported'}
     dom = rec.get('dominant', {})

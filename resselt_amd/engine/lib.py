@@ -437,7 +437,10 @@ def _warn_if_stale(path: str) -> None:
 
         if os.path.abspath(path) != os.path.abspath(B.OUT) or not os.path.isdir(B.CSRC):
             return
-        have = open(B.STAMP).read().strip() if os.path.exists(B.STAMP) else None
+        have = None
+        if os.path.exists(B.STAMP):
+            with open(B.STAMP) as f:
+                have = f.read().strip()
         if have != B._hash():
             import warnings
 
