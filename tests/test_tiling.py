@@ -136,3 +136,34 @@ def test_splits_never_yield_empty_tiles():
 
 def test_choose_grid_keeps_tile_aspect():
     assert [choose_grid(n, 1080, 1920) for n in (1, 2, 4, 8)] == [(1, 1), (1, 2), (2, 2), (2, 4)]
+
+
+def test_bench_power_sampler_matches_samples_by_wall_clock(tmp_path, monkeypatch):
+    """bench.py's power leg: a child process samples `rocm-smi` (stubbed here) and the bench keeps the samples inside its window; without
+    rocm-smi on the PATH the field is null instead of an error."""
+    import importlib.util
+    import stat
+    import sys
+    import time
+
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fake = tmp_path / 'rocm-smi'
+    fake.write_text('#!/bin/sh\necho "GPU[0]\t\t: sclk clock level: 1: (1970Mhz)"\necho "GPU[0]\t\t: Max Graphics Package Power (W): 1400.0"\n'
+                    'echo "GPU[0]\t\t: Current Socket Graphics Package Power (W): 1366.0"\n'
+                    'echo "GPU[1]\t\t: sclk clock level: S: (95Mhz)"\necho "GPU[1]\t\t: Max Graphics Package Power (W): 1400.0"\n'
+                    'echo "GPU[1]\t\t: Current Socket Graphics Package Power (W): 240.0"\n')
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv('PATH', f'{tmp_path}{os.pathsep}{os.environ["PATH"]}')
+    s = bench.PowerSampler()
+    assert s.proc is not None
+    t0 = time.time()
+    time.sleep(1.5)
+    got = s.stop(t0, time.time())
+    assert got is not None and got['samples'] >= 2 and got['avg_w'] == 1366.0 and got['cap_w'] == 1400.0 and got['sclk_mhz_avg'] == 1970  # the busy GPU
+    assert s.proc.poll() is not None  # the child is gone
+    monkeypatch.setenv('PATH', str(tmp_path / 'nothing'))
+    none = bench.PowerSampler()
+    assert none.proc is None and none.stop(0.0, time.time()) is None
+    assert sys.executable
