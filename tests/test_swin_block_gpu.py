@@ -235,3 +235,19 @@ def test_block_kernels_reject_unsupported_shapes(device):
     bp = L.SwinBlockParams()
     bp.batch, bp.H, bp.W, bp.C, bp.heads, bp.window, bp.shift, bp.hidden, bp.products = 1, 16, 16, 240, 8, 16, 0, 480, 3
     assert lib.rsa_swin_block(C.byref(bp), None) == -2  # window 16 (256 tokens) is the rect-attention path's
+
+
+def test_whole_block_with_a_large_common_offset(device):
+    """Tokens whose channels share an offset 200x their spread (mean >> std): norm1 / norm2 are two-pass (centred variance), so the
+    result stays at the oracle's; a one-pass E[x^2] - E[x]^2 in f32 would lose the variance here."""
+    from oracle.swinir import swin_block
+
+    n, C_, heads, hidden, window, h, w = 1, 240, 8, 480, 8, 16, 16
+    sd = _block_sd(C_, heads, hidden, window, 777)
+    x = _rand((n, C_, h, w), 21, 0.5) + 100.0
+    ref = swin_block(sd, 'b', x.permute(0, 2, 3, 1).reshape(n, h * w, C_), h, w, window, 4, heads).reshape(n, h, w, C_).permute(0, 3, 1, 2)
+    got, _ = _run_block(sd, x, heads, window, 4, hidden, 3, device)
+    # the block's update (ref - x) is O(1) on top of a residual stream at 100: compare the update, in its own scale
+    upd_ref, upd_got = ref - x, got - x
+    assert (upd_got - upd_ref).abs().max().item() <= 2e-3 * upd_ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
