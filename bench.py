@@ -293,7 +293,10 @@ def main():
         raise SystemExit('--config c5 has 8 tiles: --gpus must divide 8')
     if args.dry_run:
         return dry_run(args, world, rank)
-    sampler = PowerSampler() if (world == 1 and not args.no_power) else None  # (a child process: started before the first GPU call)
+    # The power sampler is a child process started before the first GPU call.  Under a profiler the GPU is already initialised by the
+    # preloaded tool library when this line runs, and a process that has touched the GPU must not start programs: no power leg then.
+    profiled = any(k.startswith(('ROCPROF', 'ROCP_', 'ROCTRACER', 'RPD_')) for k in os.environ) or 'rocprof' in os.environ.get('LD_PRELOAD', '')
+    sampler = PowerSampler() if (world == 1 and not args.no_power and not profiled) else None
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the engine has no CPU path')
     # RSA_DIST_BACKEND=gloo rehearses the N > 1 code path with several ranks on ONE GPU (RCCL refuses two ranks per device)
