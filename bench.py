@@ -53,7 +53,8 @@ def parse():
     ap.add_argument('--height', type=int, default=1080)
     ap.add_argument('--width', type=int, default=1920)
     ap.add_argument('--blocks', type=int, default=23)
-    ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'bf16'])
+    ap.add_argument('--precision', default='auto', choices=['auto', 'mixed', 'bf16x3', 'bf16'],
+                    help="auto = the engine's default policy (RRDBNet: residual dense blocks in one fp16 product, head / tail in three bf16 products)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-crop', type=int, default=256)
     ap.add_argument('--halo', type=int, default=32)
@@ -160,13 +161,17 @@ def kernel_classes(model, reps: int) -> list:
     between two HIP events on the launch stream (``reps`` launches per distinct layer shape), grouped by the kernel it dispatches to."""
     from resselt_amd.engine import lib as L
 
+    from resselt_amd.engine.base import conv_algorithmic_bytes
+
     plan = model.last_plan()
     stream = torch.cuda.current_stream().cuda_stream
     shapes: dict = {}
-    for arr in plan.conv_arrays:
+    for arr, cins in zip(plan.conv_arrays, plan.conv_cin):
         for i in range(len(arr)):
             p = arr[i]
-            key = (p.ksize, p.cin_planes, p.cout, p.H, p.W, p.upsample2x, bool(p.out_nchw), p.products)
+            # one representative per distinct launch shape: geometry, arithmetic, epilogue shape (activation, residuals, outputs)
+            key = (p.ksize, p.cin_planes, p.cout, p.H, p.W, p.upsample2x, bool(p.out_nchw), p.products, p.in_fmt, p.act, bool(p.res1), bool(p.res2),
+                   bool(p.res1_hi), bool(p.res2_hi), bool(p.out_f32), bool(p.out_lo), cins[i])  # fmt: skip
             shapes.setdefault(key, [0, arr, i])[0] += 1
     groups: dict = {}
     for key, (count, arr, i) in shapes.items():
@@ -179,13 +184,14 @@ def kernel_classes(model, reps: int) -> list:
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps
-        ks, cin_planes, cout, h, w, up, final, prod = key
-        flop = 2.0 * ks * ks * cin_planes * 8 * cout * h * w * arr[i].batch
+        ks, cout, h, w, prod, cin = key[0], key[2], key[3], key[4], key[7], key[-1]
+        flop = 2.0 * ks * ks * cin * cout * h * w * arr[i].batch  # the layer's TRUE input channels (the 3-channel first layer occupies a plane of 8)
         name = L.conv_kernel_name(arr[i])
-        g = groups.setdefault(name, {'kernel': name, 'launches': 0, 'us': 0.0, 'flop': 0.0})
+        g = groups.setdefault(name, {'kernel': name, 'launches': 0, 'us': 0.0, 'flop': 0.0, 'bytes': 0.0, 'products': prod})
         g['launches'] += count
         g['us'] += count * us
         g['flop'] += count * flop
+        g['bytes'] += count * conv_algorithmic_bytes(arr[i])
     out = []
     for g in groups.values():
         out.append({
@@ -195,6 +201,9 @@ def kernel_classes(model, reps: int) -> list:
             'ms_per_forward': round(g['us'] / 1e3, 3),
             'flop_per_launch': round(g['flop'] / g['launches']),
             'tflops': round(g['flop'] / g['us'] / 1e6, 2),
+            'products': g['products'],
+            'bytes_per_launch': round(g['bytes'] / g['launches']),  # every operand once, in the layouts this launch reads and writes
+            'gbs': round(g['bytes'] / g['us'] / 1e3, 1),
         })  # fmt: skip
     return sorted(out, key=lambda c: -c['ms_per_forward'])
 
@@ -218,11 +227,14 @@ def dry_run(args, world: int, rank: int) -> None:
 
 
 _SAMPLER = r"""
-import re, subprocess, sys, time
+import os, re, subprocess, sys, time
 out = open(sys.argv[1], 'w', buffering=1)
+start, dev = sys.argv[2], sys.argv[3]
+while not os.path.exists(start):  # idle (no process spawns, no SMU queries) until the bench reaches its power leg
+    time.sleep(0.05)
 while True:
     try:
-        txt = subprocess.run(['rocm-smi', '--showpower', '--showclocks', '--showmaxpower'], capture_output=True, text=True, timeout=10).stdout
+        txt = subprocess.run(['rocm-smi', '-d', dev, '--showpower', '--showclocks', '--showmaxpower'], capture_output=True, text=True, timeout=10).stdout
     except Exception:
         break
     t = time.time()
@@ -230,14 +242,14 @@ while True:
     ck = [float(v) for v in re.findall(r'sclk clock level: \S+ \((\d+)Mhz\)', txt)]
     cap = [float(v) for v in re.findall(r'Max Graphics Package Power \(W\): ([\d.]+)', txt)]
     if pw:
-        i = max(range(len(pw)), key=lambda k: pw[k])  # the busy GPU of the node
-        out.write(f'{t} {pw[i]} {ck[i] if i < len(ck) else 0} {cap[i] if i < len(cap) else 0}\n')
+        out.write(f'{t} {pw[0]} {ck[0] if ck else 0} {cap[0] if cap else 0}\n')
 """
 
 
 class PowerSampler:
-    """Socket power / shader clock of the busiest GPU, sampled by a CHILD process (python + rocm-smi, ~5 samples per second) that is
-    started before this process touches the GPU and never touches it itself; the samples are matched to the power leg by wall clock."""
+    """Socket power / shader clock of THIS process's GPU (the first visible device), sampled by a CHILD process (python + rocm-smi, ~5 samples
+    per second) that is started before this process touches the GPU, never touches it itself, and stays idle until ``begin()`` -- so
+    nothing is spawned or queried during model load, warm-up or the timed region; the samples are matched to the power leg by wall clock."""
 
     def __init__(self):
         import shutil
@@ -249,10 +261,18 @@ class PowerSampler:
             return
         fd, self.path = tempfile.mkstemp(prefix='rsa_power_', suffix='.txt')
         os.close(fd)
-        self.proc = subprocess.Popen([sys.executable, '-c', _SAMPLER, self.path], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        self.start_path = self.path + '.start'
+        vis = os.environ.get('HIP_VISIBLE_DEVICES') or os.environ.get('ROCR_VISIBLE_DEVICES') or '0'
+        dev = vis.split(',')[0].strip()
+        self.proc = subprocess.Popen([sys.executable, '-c', _SAMPLER, self.path, self.start_path, dev if dev.isdigit() else '0'],
+                                     stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)  # fmt: skip
         import atexit
 
         atexit.register(lambda p=self.proc: p.poll() is None and p.terminate())  # never outlives the bench
+
+    def begin(self):
+        if self.proc is not None:
+            open(self.start_path, 'w').close()  # a file: this process has initialised the GPU by now and must not start programs
 
     def stop(self, t0: float, t1: float):
         if self.proc is None:
@@ -269,13 +289,14 @@ class PowerSampler:
                 if len(v) == 4 and t0 <= float(v[0]) <= t1:
                     rows.append([float(a) for a in v])
             os.unlink(self.path)
+            os.unlink(self.start_path)
         except OSError:
             return None
         if not rows:
             return None
         pw, ck = [r[1] for r in rows], [r[2] for r in rows]
         return {'avg_w': round(sum(pw) / len(pw), 1), 'max_w': max(pw), 'cap_w': rows[-1][3] or None, 'sclk_mhz_avg': round(sum(ck) / len(ck)),
-                'samples': len(rows), 'note': 'rocm-smi socket power of the busiest GPU over the last 2 s of a 3.5 s run of back-to-back forwards (sensor averaging window ~1 s)'}  # fmt: skip
+                'samples': len(rows), 'note': 'rocm-smi socket power of this GPU over the last 2 s of a 3.5 s run of back-to-back forwards (sensor averaging window ~1 s)'}  # fmt: skip
 
 
 def main():
@@ -369,6 +390,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the ring schedule's failure word (rsa_check_status; the stream is synchronised): a timed-out hand-off means wrong pixels, so no line
+    from resselt_amd.engine import lib as L
+
+    L.check_status('bench: timed region')
+    aborts = L.ring_aborts()
+    if aborts != 0:
+        raise SystemExit(f'bench.py: {aborts} ring-schedule hand-offs timed out; the timed forwards are invalid')
+
     total_out_px = y.shape[-1] * y.shape[-2] * y.shape[0]  # whole image (on every rank after the all-gather)
     assert total_out_px == 16 * img_h * img_w
     ms_per_step = dt / args.steps * 1e3
@@ -397,14 +426,25 @@ def main():
         achieved_tf = flop / kern_s / 1e12
         achieved_gbs = HBM_B_PER_OUT_PX * out_px / kern_s / 1e9
         layout_bytes = model.conv_bytes_per_forward()  # same layer-wise model, priced in this engine's split-plane/f32-map layouts
-        nprod = 3 if args.precision == 'bf16x3' else 1
+        prec = model.resolved_precision()
+        prec_note = {
+            'mixed': 'residual-dense-block convolutions (92 % of the MACs) in ONE fp16 product on hi planes, conv_first / upsampling / HR / last '
+                     'convolutions in three bf16 products on split planes, trunk convolution in three fp16 products; f32 accumulate',
+            'bf16x3': 'bf16 MFMA operands split hi+lo (3 products), f32 accumulate',
+            'bf16': 'plain bf16 MFMA operands, f32 accumulate',
+        }[prec]  # fmt: skip
         if args.no_kernel_roofline:
             classes = [{'kernel': 'all conv launches of one forward (per-kernel replays skipped)', 'launches': n_launch, 'avg_us': round(kern_s / n_launch * 1e6, 2),
                         'ms_per_forward': round(kern_s * 1e3, 3), 'flop_per_launch': round(flop / n_launch), 'tflops': round(achieved_tf, 2)}]  # fmt: skip
         else:
             classes = kernel_classes(model, max(2, min(args.steps, 5)))
         dom = max(classes, key=lambda c: c['ms_per_forward'])
-        traffic = measured_traffic() if (args.precision == 'bf16x3' and (H, W, args.blocks) == (1080, 1920, 23)) else {'bytes': None, 'note': 'PMC traffic is only collected for the default workload'}
+        issued_tf = sum(c['tflops'] * c.get('products', 1) * c['ms_per_forward'] for c in classes) / max(1e-9, sum(c['ms_per_forward'] for c in classes))
+        traffic = measured_traffic() if (prec == 'mixed' and (H, W, args.blocks) == (1080, 1920, 23)) else {'bytes': None, 'note': 'PMC traffic is only collected for the default workload'}
+        # which roof the dominant kernel is nearer to: its algorithmic FLOP rate over the dense MFMA peak, or its algorithmic bytes (every
+        # operand once, in the layouts it reads and writes) per second over the HBM peak
+        dom_mfma, dom_hbm = dom['tflops'] / MFMA_PEAK_TFLOPS, dom.get('gbs', 0.0) / HBM_PEAK_GBS
+        dom_bound = 'hbm' if dom_hbm > dom_mfma else 'mfma'
         tile_note = {
             'c2': f'{rows}x{cols} tiles of {H}x{W} (+{args.halo} px input halo), one per GPU, RCCL all-gather of fp32 output tiles' if world > 1 else 'single tile',
             'c5': f'one 3x{img_h}x{img_w} input, 2x4 tiles of {2 * H}x{W} (+{args.halo} px halo) dealt round-robin to {world} rank(s), each run as 1080p-sized sub-tiles; '
@@ -421,31 +461,34 @@ def main():
             'higher_is_better': True,
             'scaling': 'strong' if args.config == 'c5' else 'weak',
             'vs_baseline': None,
-            'dtype': 'bf16',
+            'dtype': 'fp16' if prec == 'mixed' else 'bf16',  # the arithmetic type of the dominant layers (config.precision names the whole policy)
             'data': 'synthetic',
             'config': {
                 'workload': (f'RealESRGAN-x4plus (RRDBNet nf64 nb{args.blocks} gc32 x4), 1x3x{H}x{W} fp32 frame per GPU -> 1x3x{4 * H}x{4 * W}, ' if args.config == 'c2' else
                              f'RealESRGAN-x4plus (RRDBNet nf64 nb{args.blocks} gc32 x4), ONE 1x3x{img_h}x{img_w} fp32 image -> 1x3x{4 * img_h}x{4 * img_w} over all GPUs (BASELINE configs[4]), ')
-                + ('bf16 MFMA operands split hi+lo (3 products), f32 accumulate' if args.precision == 'bf16x3' else 'plain bf16 MFMA operands, f32 accumulate')
-                + ', synthetic uniform(+-1/sqrt(fan_in)) weights',
-                'precision': args.precision,
+                + prec_note + ', synthetic uniform(+-1/sqrt(fan_in)) weights',
+                'precision': args.precision if args.precision == prec else f'{args.precision} -> {prec}',
+                'precision_policy': prec_note,
                 'tile_parallel': tile_note,
                 'launches_per_step': n_launch,
             },
             # the DOMINANT kernel (largest share of the frame), timed live per launch with HIP events on the launch stream
             'roofline': {
-                'bound': 'mfma',
+                'bound': dom_bound,
                 'kernel': dom['kernel'],
-                'achieved': dom['tflops'],
-                'peak': MFMA_PEAK_TFLOPS,
-                'unit': 'TFLOP/s',
-                'frac': round(dom['tflops'] / MFMA_PEAK_TFLOPS, 4),
+                'achieved': dom['gbs'] if dom_bound == 'hbm' else dom['tflops'],
+                'peak': HBM_PEAK_GBS if dom_bound == 'hbm' else MFMA_PEAK_TFLOPS,
+                'unit': 'GB/s' if dom_bound == 'hbm' else 'TFLOP/s',
+                'frac': round(max(dom_hbm, dom_mfma), 4),
+                'frac_mfma': round(dom_mfma, 4),
+                'frac_hbm': round(dom_hbm, 4),
+                'bytes_per_launch': dom.get('bytes_per_launch'),
                 'traffic': traffic['bytes'],
                 'traffic_note': traffic['note'],
                 'avg_launch_us': dom['avg_us'],
                 'launches_per_forward': dom['launches'],
                 'flop_per_launch': dom['flop_per_launch'],
-                'mfma_issued_frac': round(dom['tflops'] * nprod / MFMA_PEAK_TFLOPS, 4),
+                'mfma_issued_frac': round(dom['tflops'] * dom.get('products', 1) / MFMA_PEAK_TFLOPS, 4),
                 'share_of_frame': round(dom['ms_per_forward'] / (kern_s * 1e3), 3),
             },
             'roofline_kernels': classes,  # every kernel class of the forward, same definitions
@@ -455,7 +498,7 @@ def main():
                 'peak': MFMA_PEAK_TFLOPS,
                 'unit': 'TFLOP/s',
                 'frac': round(achieved_tf / MFMA_PEAK_TFLOPS, 4),
-                'mfma_issued_frac': round(achieved_tf * nprod / MFMA_PEAK_TFLOPS, 4),
+                'mfma_issued_frac': round(issued_tf / MFMA_PEAK_TFLOPS, 4),
                 'note': f'all {n_launch} launches of one forward: 2,240,856 algorithmic FLOP per output pixel / event time of the forward',
             },
             'roofline_hbm': {
@@ -467,12 +510,14 @@ def main():
                 'model': 'layer-wise bf16 bytes, 7,790 B per output pixel (SURVEY.md 8d)',
                 'layout_bytes_per_launch': None if not layout_bytes else round(layout_bytes / n_launch),
                 'layout_achieved': None if not layout_bytes else round(layout_bytes / kern_s / 1e9, 1),
-                'layout_note': 'the same every-operand-once model priced in the engine layouts (hi+lo bf16 planes = 4 B/channel for 3 products)',
+                'layout_note': 'the same every-operand-once model priced in the engine layouts (split planes hi+lo = 4 B/channel where a layer reads or writes both halves, 2 B/channel for hi-only fp16 planes)',
             },
+            'ring_aborts': aborts,
             'event_ms_per_step': round(ev_ms / args.steps, 3),
             'forward_ms_1080p': round(kern_s * 1e3, 3),
         }
         if sampler is not None:  # power leg: 3.5 s of back-to-back forwards, the last 2 s of samples
+            sampler.begin()
             w0 = time.time()
             while time.time() - w0 < 3.5:
                 model(xt)

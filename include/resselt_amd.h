@@ -34,13 +34,15 @@
 extern "C" {
 #endif
 
-#define RSA_VERSION 200 /* 0.2.0: rsa_conv_params.w_layout, rsa_pack_weights, ring schedule */
+#define RSA_VERSION 300 /* 0.3.0: plane formats (fp16 one-product mode), rsa_check_status, rsa_pack_weights(fmt) */
 
 /* error codes (negative = argument errors) */
 #define RSA_OK 0
 #define RSA_E_ARG (-1)       /* null / out-of-range argument */
 #define RSA_E_UNSUPPORTED (-2) /* combination not compiled in */
 #define RSA_E_ALIGN (-3)     /* pointer not 16-byte aligned */
+#define RSA_E_INTERNAL (-4)  /* a kernel reported a protocol failure (ring schedule hand-off timed out): results of the launches since the
+                                last rsa_check_status() == RSA_OK are not to be trusted */
 
 /* activation selector of the fused epilogue */
 enum rsa_act {
@@ -59,6 +61,14 @@ enum rsa_act {
  *   write (rsa_conv2d final store):       byte = round-half-even(clamp(v, 0, 1) * 255)   (torch: (y.clamp(0, 1) * 255).round()) */
 enum rsa_dtype { RSA_F32 = 0, RSA_F16 = 1, RSA_BF16 = 2, RSA_U8 = 3 };
 
+/* 16-bit element format of split planes and packed weights.  A plane buffer has ONE format; `hi` is the round-to-nearest-even of the f32
+ * value in that format and `lo` (optional) the same rounding of the residual v - hi:
+ *   RSA_PF_BF16: 8 + 8 significant bits with both halves, f32 range                       -> v_mfma_f32_16x16x32_bf16
+ *   RSA_PF_F16 : 11 significant bits with hi alone, 22 with both, |v| < 65504             -> v_mfma_f32_16x16x32_f16
+ * The one-product fp16 mode (products == 1, in_fmt == RSA_PF_F16) reads hi only: a third of the matrix instructions and half the
+ * activation bytes of products == 3; the engine's `precision = 'auto'` uses it where the error budget allows. */
+enum rsa_plane_fmt { RSA_PF_BF16 = 0, RSA_PF_F16 = 1 };
+
 /*
  * One fused convolution launch.
  *
@@ -69,9 +79,9 @@ enum rsa_dtype { RSA_F32 = 0, RSA_F16 = 1, RSA_BF16 = 2, RSA_U8 = 3 };
  * :340-344 (RRDB.forward), :83-91 (ShortcutBlock), :510-537 (upconv_block), :477-507
  * (pixelshuffle_block); archs/spanplus/arch.py:94-130; archs/swinir/arch.py:34-40 (Linear = k1 conv).
  *
- * Arithmetic: implicit GEMM on v_mfma_f32_16x16x32_bf16, f32 accumulate.
- *   products == 1 : acc += hi(a)*hi(w)                                 ("bf16")
- *   products == 3 : acc += hi(a)*hi(w) + lo(a)*hi(w) + hi(a)*lo(w)     ("bf16x3", ~16-bit operands)
+ * Arithmetic: implicit GEMM on v_mfma_f32_16x16x32_bf16 / _f16 (in_fmt), f32 accumulate.
+ *   products == 1 : acc += hi(a)*hi(w)                                 ("bf16" / "fp16")
+ *   products == 3 : acc += hi(a)*hi(w) + lo(a)*hi(w) + hi(a)*lo(w)     ("bf16x3": ~16-bit operands; "fp16x3": ~22-bit)
  */
 typedef struct rsa_conv_params {
   /* geometry */
@@ -132,11 +142,23 @@ typedef struct rsa_conv_params {
   const void* res2_lo;
   int64_t res_plane_stride;
   int64_t res_batch_stride;
+  /* enum rsa_plane_fmt of the three plane operands (0 = bf16, the default of a zeroed descriptor) */
+  int32_t in_fmt;   /* in_hi / in_lo AND w_packed: selects the matrix instruction */
+  int32_t out_fmt;  /* out_hi / out_lo */
+  int32_t res_fmt;  /* res1_hi / res1_lo / res2_hi / res2_lo */
+  int32_t reserved0; /* must be 0 */
 } rsa_conv_params;
 
-/* Launch `n` fused convolutions in order on `stream` (one host call per forward pass). */
+/* Launch `n` fused convolutions in order on `stream` (one host call per forward pass).  Both return RSA_E_INTERNAL, without launching,
+ * when a kernel of an EARLIER call has reported a protocol failure that rsa_check_status has not yet been asked about. */
 int rsa_conv2d(const rsa_conv_params* p, void* stream);
 int rsa_conv2d_list(const rsa_conv_params* list, int32_t n, void* stream);
+
+/* Failure word of the ring schedule (csrc/conv_ring.h: a hand-off between the loader wave and the compute waves that timed out makes the
+ * kernel drain with wrong pixels).  The kernels report into host-visible memory, so this call never synchronises: it sees the failures of
+ * every launch that has COMPLETED.  Call it after the stream (or an event behind the forward) has been synchronised to judge that forward.
+ * Returns RSA_OK, or RSA_E_INTERNAL once (the word is cleared; rsa_last_error_string says how many hand-offs failed). */
+int rsa_check_status(void);
 
 /* Bytes of the packed weight blob for a (cout, cin_planes, ksize, products) convolution. */
 int64_t rsa_packed_weight_bytes(int32_t cout, int32_t cin_planes, int32_t ksize, int32_t products);
@@ -158,17 +180,19 @@ int rsa_conv_cout_tiles(int32_t cout);
  *   2  the same per 16-channel half chunk, five K steps each (an odd number of half chunks, e.g. 48 input channels)
  *   3  nearest x2 upsampling + 3x3 as four 2x2 phase convolutions on the source map, taps pre-summed (64 -> 64 channels;
  *      resselt_amd/csrc/conv_ring_up.h)
- * (hi = bf16 RNE of w, lo = bf16 of w - hi; only hi when products == 1).
+ * (hi = RNE of w in `fmt` (enum rsa_plane_fmt), lo = the same rounding of w - hi; only hi when products == 1).
  */
 int rsa_conv_weight_layout(const rsa_conv_params* p);
 int rsa_pack_weights(const float* w_oihw, int32_t cout, int32_t cin, int32_t cin_planes, int32_t ksize, int32_t products, int32_t layout,
-                     void* out, void* stream);
+                     int32_t fmt, void* out, void* stream);
 
 /* Name of the kernel a descriptor dispatches to (matches the rocprofv3 kernel names; bench.py groups its rooflines by it). */
 const char* rsa_conv_kernel_name(const rsa_conv_params* p);
 
 /* Debug: spins of the ring schedule's LDS hand-offs that ran into their bound (always 0 in a correct build; tests assert it). */
 int rsa_debug_ring_aborts(void);
+/* Debug: polls a hand-off of the ring schedule may spend before it gives up (default 2^18; 1 forces the failure path: tests). */
+int rsa_debug_set_ring_spin_limit(int32_t polls);
 /* Debug: force the ring schedule on (1) / off (0) for descriptors built afterwards, or follow RSA_CONV_RING again (-1).  Descriptors carry
  * the layout they were built for, so change it only between building descriptor sets (in-process A/B timing). */
 int rsa_debug_set_ring(int32_t mode);
@@ -183,11 +207,11 @@ int rsa_debug_set_ring(int32_t mode);
  */
 int rsa_nchw_to_planes(const void* x, int32_t dtype, int32_t batch, int32_t C, int32_t H, int32_t W, int32_t src_h, int32_t src_w,
                        int32_t unshuffle, const float* mean, float scale, void* out_hi, void* out_lo, int64_t out_plane_stride,
-                       int64_t out_batch_stride, void* stream);
+                       int64_t out_batch_stride, int32_t out_fmt, void* stream);
 
 /* split planes / f32 NCHW4c -> plain NCHW (debug + parity of intermediates) */
 int rsa_planes_to_nchw(const void* hi, const void* lo, int64_t plane_stride, int64_t batch_stride, int32_t batch,
-                       int32_t C, int32_t H, int32_t W, float* out, void* stream);
+                       int32_t C, int32_t H, int32_t W, int32_t fmt, float* out, void* stream);
 
 /*
  * DySample upsampler head: sigmoid-gated learned offsets -> bilinear border gather over channel groups -> 1x1 conv.

@@ -19,7 +19,8 @@ import torch
 
 from ...engine import lib as L
 from ...engine import ops
-from ...engine.base import EngineModule, Plan
+from ...engine.base import EngineModule, Fp16Range, Plan
+from ...engine.tensors import PF_BF16, PF_F16
 from ...engine.paramtree import build_param_tree
 
 _GC = 32  # growth channels are fixed by the reference ctor (arch.py:88)
@@ -89,6 +90,22 @@ def new_arch_to_old(state_dict) -> dict:
 class RRDBNet(EngineModule):
     hyperparameters = {}
     supports_u8 = True  # uint8 [N, H, W, C] images: /255 in the layout kernel, clamp*255+round in the last convolution's store
+    # 'mixed' (what 'auto' selects): the convolutions inside residual dense blocks -- 92 % of the multiply-accumulates, attenuated by the
+    # 0.2 * 0.2 residual scalings -- run ONE fp16 product on hi planes; conv_first, the upsampling / HR / last convolutions run three bf16
+    # products and the trunk convolution three fp16 products on the fp16 residual stream.  Measured against the fp32 oracle on RRDBNet-23:
+    # 1.2e-4 max-abs (uniform synthetic weights), 9e-5 (heavy-tailed), where 'bf16x3' gives 2.6e-5 and one product everywhere 1.9e-3
+    # (tests/test_precision_policy.py emulates the table on the CPU; tests/test_baseline_configs_gpu.py pins the kernels).
+    auto_precision = 'mixed'
+    precisions = ('bf16x3', 'bf16', 'mixed')
+
+    @staticmethod
+    def layer_policy(name: str) -> tuple[int, int]:
+        """(products, plane format of the inputs and weights) of convolution ``name`` under 'mixed'."""
+        if '.RDB' in name:
+            return 1, PF_F16
+        if name.startswith('model.1.sub.'):  # the trunk convolution: reads the fp16 residual stream (hi + lo)
+            return 3, PF_F16
+        return 3, PF_BF16
 
     def __init__(self, in_nc: int = 3, out_nc: int = 3, num_filters: int = 64, num_blocks: int = 23, scale: int = 4,
                  plus: bool = False, shuffle_factor: int | None = None) -> None:  # fmt: skip
@@ -104,6 +121,10 @@ class RRDBNet(EngineModule):
         self.scale = scale // shuffle_factor if shuffle_factor else scale
         self.tail_band_rows = 272  # low-resolution rows per band of the 2x / 4x tail (bounds the plan's HR buffers; >= image height: one band)
         self.plane_residuals = True  # residual stream kept as split planes only (False: the f32-map plan; A/B and plain-bf16 mode)
+        if plus or num_filters != 64:
+            # the 'mixed' table is built for the x4plus / x2plus / ESRGAN trunk (64 channels: the fp16x3 trunk convolution is the four-tile
+            # ring kernel); ESRGAN+ adds f32 side maps it has no plan for.  Such checkpoints run the conservative mode under 'auto'.
+            self.auto_precision = 'bf16x3'
         build_param_tree(self, rrdbnet_param_shapes(in_nc, out_nc, num_filters, num_blocks, scale, plus))
 
     def _convert_state_dict(self, state_dict):
@@ -128,11 +149,20 @@ class RRDBNet(EngineModule):
     # ---------------------------------------------------------------- weights
     def _pack(self, device, products):
         sd = {k: v.detach() for k, v in self.state_dict().items()}
+        mixed = products.name == 'mixed'
+        if mixed and self.plus:
+            raise NotImplementedError("ESRGAN+ (conv1x1 branch) has no 'mixed' plan; use precision = 'bf16x3'")
         out = {}
+        amax = []
         for name in sd:
             if name.endswith('.weight'):
                 base = name[: -len('.weight')]
-                out[base] = ops.ConvWeights.from_oihw(sd[name], sd.get(f'{base}.bias'), products, device=device)
+                prod, fmt = self.layer_policy(base) if mixed else (int(products), products.fmt)
+                out[base] = ops.ConvWeights.from_oihw(sd[name], sd.get(f'{base}.bias'), prod, device=device, fmt=fmt)
+                if fmt == PF_F16:
+                    amax.append(out[base].w.abs().amax())
+        if amax and float(torch.stack(amax).amax()) > 6.0e4:  # one synchronisation per pack: the fp16 range guard
+            raise Fp16Range('a convolution weight exceeds the fp16 range (|w| > 6e4)')
         return out
 
     # ---------------------------------------------------------------- plan
@@ -151,6 +181,7 @@ class RRDBNet(EngineModule):
             raise RuntimeError(f'model expects {self.in_nc // (sf * sf if sf else 1)} input channels, got {c}')
         nf, nb, gc = self.nf, self.nb, _GC
         with_lo = products == 3
+        mixed = products.name == 'mixed'
         pf, pg = nf // 8, gc // 8
         x_pl = plan.planes(n, (c_net + 7) // 8, h, w, with_lo)
         # The residual stream x of the RDBs lives ONLY as the split planes the next convolution reads (hi + lo, ~16 bits; measured
@@ -159,8 +190,13 @@ class RRDBNet(EngineModule):
         # input (workspace 0, planes 0..pf) is still intact when RDB3's conv5 adds it, and is then overwritten in place by that
         # same launch (each lane reads its residual elements before it stores them).  Plain-bf16 mode has no lo planes and keeps
         # the f32 residual maps (a bf16 residual stream would lose what little accuracy that mode has).
-        plane_res = with_lo and self.plane_residuals
-        ws = [plan.planes(n, pf + 4 * pg, h, w, with_lo) for _ in range(3 if plane_res else 2)]
+        # 'mixed': the workspaces are fp16; the trunk channels x (planes 0..pf) keep hi + lo -- the residual stream, 22 bits -- and the growth
+        # channels x1..x4 hi only (their one-product consumers never read lo): 2 bytes per channel read and written instead of 4.
+        plane_res = mixed or (with_lo and self.plane_residuals)
+        if mixed:
+            ws = [plan.planes(n, pf + 4 * pg, h, w, True, PF_F16, lo_planes=pf) for _ in range(3)]
+        else:
+            ws = [plan.planes(n, pf + 4 * pg, h, w, with_lo) for _ in range(3 if plane_res else 2)]
         fea = plan.f32map(n, nf, h, w)
         pool = [] if plane_res else [plan.f32map(n, nf, h, w) for _ in range(4)]
         lrelu = dict(act=L.ACT_LRELU, act_param=0.2)

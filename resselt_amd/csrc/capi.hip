@@ -32,9 +32,22 @@ __device__ __forceinline__ float ld_as_float(const void* p, int64_t i) {
 // (F.pad(..., 'reflect') to the right/bottom, resselt/utilities/padding.py:24-29 as used by SwinIR.check_image_size)
 // unshuffle = r > 1: torch.pixel_unshuffle(x, r) fused into the read: plane channel c*r*r + i*r + j at (y, x) comes from source
 // channel c at (y*r + i, x*r + j) (RRDBNet x2plus / x1 front end, archs/esrgan/arch.py:130-137); C is then the SOURCE channel count.
+typedef __attribute__((ext_vector_type(8))) uint16_t u16x8;
+__device__ __forceinline__ void split_elem(float v, int fmt, uint16_t& hi, uint16_t& lo) {  // (hi, lo) halves of plane format fmt
+  if (fmt == RSA_PF_F16) {
+    const _Float16 h = (_Float16)v;
+    hi = __builtin_bit_cast(uint16_t, h);
+    lo = __builtin_bit_cast(uint16_t, (_Float16)(v - (float)h));
+  } else {
+    const __bf16 h = (__bf16)v;
+    hi = __builtin_bit_cast(uint16_t, h);
+    lo = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)h));
+  }
+}
+
 __global__ void nchw_to_planes_kernel(const void* x, int dtype, int batch, int C, int H, int W, int srcH, int srcW, int unshuffle,
                                       const float* mean, float scale, void* out_hi, void* out_lo, int64_t plane_stride,
-                                      int64_t batch_stride) {
+                                      int64_t batch_stride, int fmt) {
   const int r2 = unshuffle * unshuffle;
   const int Cp = C * r2;  // channels of the planes
   const int planes = (Cp + 7) >> 3;
@@ -47,7 +60,7 @@ __global__ void nchw_to_planes_kernel(const void* x, int dtype, int batch, int C
     const int pl = (int)(t % planes);
     const int n = (int)(t / planes);
     const int py = (int)(pix / W), px = (int)(pix % W);
-    bf16x8 h, l;
+    u16x8 h, l;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int cp = pl * 8 + j;
@@ -70,13 +83,14 @@ __global__ void nchw_to_planes_kernel(const void* x, int dtype, int batch, int C
         if (mean != nullptr) v -= mean[c];  // per SOURCE channel
         v *= scale;
       }
-      const __bf16 hb = (__bf16)v;
+      uint16_t hb, lb;
+      split_elem(v, fmt, hb, lb);
       h[j] = hb;
-      l[j] = (__bf16)(v - (float)hb);
+      l[j] = lb;
     }
     const int64_t unit = (int64_t)n * batch_stride + (int64_t)pl * plane_stride + pix;
-    ((bf16x8*)out_hi)[unit] = h;
-    if (out_lo != nullptr) ((bf16x8*)out_lo)[unit] = l;
+    ((u16x8*)out_hi)[unit] = h;
+    if (out_lo != nullptr) ((u16x8*)out_lo)[unit] = l;
   }
 }
 
@@ -116,7 +130,7 @@ __global__ void nchw_to_image_u8_kernel(const void* x, int dtype, int batch, int
 
 
 __global__ void planes_to_nchw_kernel(const void* hi, const void* lo, int64_t plane_stride, int64_t batch_stride, int batch, int C, int H,
-                                      int W, float* out) {
+                                      int W, int fmt, float* out) {
   const int64_t HW = (int64_t)H * W;
   const int64_t total = (int64_t)batch * C * HW;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -125,8 +139,8 @@ __global__ void planes_to_nchw_kernel(const void* hi, const void* lo, int64_t pl
     const int c = (int)(t % C);
     const int n = (int)(t / C);
     const int64_t e = ((int64_t)n * batch_stride + (int64_t)(c >> 3) * plane_stride + pix) * 8 + (c & 7);
-    float v = (float)((const __bf16*)hi)[e];
-    if (lo != nullptr) v += (float)((const __bf16*)lo)[e];
+    float v = fmt == RSA_PF_F16 ? (float)((const _Float16*)hi)[e] : (float)((const __bf16*)hi)[e];
+    if (lo != nullptr) v += fmt == RSA_PF_F16 ? (float)((const _Float16*)lo)[e] : (float)((const __bf16*)lo)[e];
     out[idx] = v;
   }
 }
@@ -177,6 +191,13 @@ const char* rsa_conv_kernel_name(const rsa_conv_params* p) { return p == nullptr
 
 int rsa_debug_ring_aborts(void) { return (int)rsa::conv_ring_aborts(); }
 
+int rsa_check_status(void) { return rsa::conv_check_status(); }
+
+int rsa_debug_set_ring_spin_limit(int32_t polls) {
+  rsa::conv_set_ring_spin_limit(polls);
+  return RSA_OK;
+}
+
 int rsa_debug_set_ring(int32_t mode) {
   rsa::conv_ring_override(mode);
   return RSA_OK;
@@ -192,7 +213,8 @@ int64_t rsa_packed_weight_bytes(int32_t cout, int32_t cin_planes, int32_t ksize,
 
 int rsa_nchw_to_planes(const void* x, int32_t dtype, int32_t batch, int32_t C, int32_t H, int32_t W, int32_t src_h, int32_t src_w,
                        int32_t unshuffle, const float* mean, float scale, void* out_hi, void* out_lo, int64_t out_plane_stride,
-                       int64_t out_batch_stride, void* stream) {
+                       int64_t out_batch_stride, int32_t out_fmt, void* stream) {
+  if (out_fmt != RSA_PF_BF16 && out_fmt != RSA_PF_F16) return rsa::set_error(RSA_E_ARG, "nchw_to_planes: out_fmt must be an rsa_plane_fmt");
   if (unshuffle < 1) return rsa::set_error(RSA_E_ARG, "nchw_to_planes: unshuffle must be >= 1");
   if (x == nullptr || out_hi == nullptr || batch < 1 || C < 1 || H < 1 || W < 1) return rsa::set_error(RSA_E_ARG, "nchw_to_planes: bad argument");
   {
@@ -204,17 +226,18 @@ int rsa_nchw_to_planes(const void* x, int32_t dtype, int32_t batch, int32_t C, i
   if (((uintptr_t)out_hi | (uintptr_t)out_lo) & 15) return rsa::set_error(RSA_E_ALIGN, "nchw_to_planes: outputs must be 16-byte aligned");
   const int64_t total = (int64_t)batch * ((C * unshuffle * unshuffle + 7) / 8) * H * W;
   hipLaunchKernelGGL(rsa::nchw_to_planes_kernel, dim3(rsa::grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, dtype, batch, C, H, W,
-                     src_h, src_w, unshuffle, mean, scale, out_hi, out_lo, out_plane_stride, out_batch_stride);
+                     src_h, src_w, unshuffle, mean, scale, out_hi, out_lo, out_plane_stride, out_batch_stride, out_fmt);
   const int rc = (int)hipGetLastError();
   return rc ? rsa::set_error(rc, "nchw_to_planes: launch failed") : RSA_OK;
 }
 
 int rsa_planes_to_nchw(const void* hi, const void* lo, int64_t plane_stride, int64_t batch_stride, int32_t batch, int32_t C, int32_t H, int32_t W,
-                       float* out, void* stream) {
+                       int32_t fmt, float* out, void* stream) {
+  if (fmt != RSA_PF_BF16 && fmt != RSA_PF_F16) return rsa::set_error(RSA_E_ARG, "planes_to_nchw: fmt must be an rsa_plane_fmt");
   if (hi == nullptr || out == nullptr || batch < 1 || C < 1 || H < 1 || W < 1) return rsa::set_error(RSA_E_ARG, "planes_to_nchw: bad argument");
   const int64_t total = (int64_t)batch * C * H * W;
   hipLaunchKernelGGL(rsa::planes_to_nchw_kernel, dim3(rsa::grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, hi, lo, plane_stride,
-                     batch_stride, batch, C, H, W, out);
+                     batch_stride, batch, C, H, W, fmt, out);
   const int rc = (int)hipGetLastError();
   return rc ? rsa::set_error(rc, "planes_to_nchw: launch failed") : RSA_OK;
 }

@@ -25,18 +25,24 @@ enum { RSA_WL_TAPS = 0, RSA_WL_PAIRS = 1, RSA_WL_HALFPAIRS = 2, RSA_WL_UPPHASE =
 // with three cout tiles (the 48 -> 48 layers of the SPAN family: half mode).  RSA_CONV_RING=0 in the environment switches the schedule off (A/B runs).
 bool conv_ring_enabled();
 void conv_ring_override(int v);
+// Round 3: the same schedule in ONE product on fp16 hi planes (every shape, no fused upsampling), and in three fp16 products for the
+// four-tile shape (the trunk convolution of RRDBNet under the 'auto' precision policy reads the fp16 residual stream).
 inline bool conv_ring_eligible(const rsa_conv_params& p) {
   const int ct = (p.cout + 15) / 16;
-  if (p.ksize != 3 || p.products != 3 || p.cin_planes < 2 || (p.cin_planes & 1)) return false;
+  if (p.ksize != 3 || p.cin_planes < 2 || (p.cin_planes & 1)) return false;
+  const bool whole = (p.cin_planes & 3) == 0;
+  if (p.products == 3 && p.in_fmt == RSA_PF_F16) return whole && ct == 4 && !p.upsample2x && p.out_nchw == nullptr;
+  if (p.products == 1 && p.in_fmt != RSA_PF_F16) return false;  // plain-bf16 mode stays on the chunk-barrier kernels
+  if (p.products == 1 && p.upsample2x) return false;
   if (p.out_nchw != nullptr) return ct == 3 && !p.upsample2x;  // final stores: the three-tile shape only (the pixel-shuffle heads of SPAN / Compact)
-  if ((p.cin_planes & 3) == 0) return ct == 2 || ct == 4 || (ct == 3 && !p.upsample2x);
+  if (whole) return ct == 2 || ct == 4 || (ct == 3 && !p.upsample2x);
   return ct == 3 && !p.upsample2x;
 }
 // Nearest x2 upsampling + 3x3 as four 2x2 phase convolutions on the source map (conv_ring_up.h): 64 -> 64 channels, LeakyReLU / none,
 // split-plane output only -- the upconv layers of RRDBNet and of SwinIR's nearest+conv head.  RSA_CONV_UP2=0 switches it off (A/B runs).
 bool conv_up2_enabled();
 inline bool conv_ring_up2_eligible(const rsa_conv_params& p) {
-  return p.ksize == 3 && p.products == 3 && p.upsample2x && p.cin_planes == 8 && p.cout == 64 && !(p.H & 1) && !(p.W & 1) && p.out_hi != nullptr &&
+  return p.ksize == 3 && p.products == 3 && p.in_fmt == RSA_PF_BF16 && p.out_fmt == RSA_PF_BF16 && p.upsample2x && p.cin_planes == 8 && p.cout == 64 && !(p.H & 1) && !(p.W & 1) && p.out_hi != nullptr &&
          p.out_lo != nullptr && p.out_f32 == nullptr && p.out_nchw == nullptr && p.res1 == nullptr && p.res2 == nullptr && p.res1_hi == nullptr &&
          p.res2_hi == nullptr && (p.act == RSA_ACT_NONE || (p.act == RSA_ACT_LRELU && p.act_param >= 0.f && p.act_param <= 1.f));
 }
@@ -52,5 +58,15 @@ int conv_launch_ring_up2(const rsa_conv_params& p, hipStream_t stream);
 // bytes of a packed blob in a given layout (layout 3 is larger than the chunked ones: 32 K steps per 64 x 64 layer)
 int64_t packed_weight_bytes(int cout, int cin_planes, int ksize, int products, int layout);
 unsigned int conv_ring_aborts();
+// What the launcher hands every ring kernel beside the descriptor: the host-visible failure word (pinned, device-mapped; a timed-out hand-off
+// adds to it and rsa_check_status reads it without a synchronisation) and the bound of a spin (rsa_debug_set_ring_spin_limit).
+struct RingAux {
+  unsigned int* fail_word;
+  int spin_limit;
+};
+RingAux ring_aux();  // conv_mfma.hip
+// host-visible failure word of the ring kernels (conv_mfma.hip): 0 = nothing to report, else RSA_E_INTERNAL with the count in the error string
+int conv_check_status();
+void conv_set_ring_spin_limit(int polls);
 
 }  // namespace rsa

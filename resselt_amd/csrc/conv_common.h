@@ -9,12 +9,24 @@
 
 namespace rsa {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;  // also the 128-bit container of an fp16 fragment (bit-cast at the MFMA)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 constexpr int NPL = 4;  // planes per K chunk (32 channels = one MFMA K)
+
+// D[16][16] += A[16][32] * B[32][16] on 16-bit fragments of plane format FMT (enum rsa_plane_fmt: 0 = bf16, 1 = fp16); same fragment
+// layout, same cycles
+template <int FMT>
+__device__ __forceinline__ f32x4 mfma16(const bf16x8 a, const bf16x8 b, const f32x4 c) {
+  if constexpr (FMT == RSA_PF_F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 
 // Activation CLASS of an epilogue instantiation.  The epilogue is compiled once per class and selected by ONE wave-uniform
 // switch per tile: with a per-value runtime switch every one of the 64 value sites of the unrolled epilogue carried the inlined
@@ -96,14 +108,43 @@ __device__ __forceinline__ void wg_barrier() {
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// (a, b) -> packed bf16 pair (RNE) and the pair's rounding residuals, also packed
+// (a, b) -> packed 16-bit pair (RNE) of plane format FMT and the pair's rounding residuals, also packed
+template <int FMT = 0>
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
-  const bf16x2 h = {(__bf16)a, (__bf16)b};
-  hi = __builtin_bit_cast(uint32_t, h);
-  const float ra = a - __builtin_bit_cast(float, hi << 16);
-  const float rb = b - __builtin_bit_cast(float, hi & 0xffff0000u);
-  const bf16x2 l = {(__bf16)ra, (__bf16)rb};
-  lo = __builtin_bit_cast(uint32_t, l);
+  if constexpr (FMT == RSA_PF_F16) {
+    const f16x2 h = {(_Float16)a, (_Float16)b};
+    hi = __builtin_bit_cast(uint32_t, h);
+    const f16x2 l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+    lo = __builtin_bit_cast(uint32_t, l);
+  } else {
+    const bf16x2 h = {(__bf16)a, (__bf16)b};
+    hi = __builtin_bit_cast(uint32_t, h);
+    const float ra = a - __builtin_bit_cast(float, hi << 16);
+    const float rb = b - __builtin_bit_cast(float, hi & 0xffff0000u);
+    const bf16x2 l = {(__bf16)ra, (__bf16)rb};
+    lo = __builtin_bit_cast(uint32_t, l);
+  }
+}
+// runtime format (wave-uniform): the generic epilogue
+__device__ __forceinline__ void split2_rt(bool f16, float a, float b, uint32_t& hi, uint32_t& lo) {
+  if (f16)
+    split2<RSA_PF_F16>(a, b, hi, lo);
+  else
+    split2<RSA_PF_BF16>(a, b, hi, lo);
+}
+// four channels of a unit half: hi (+ lo) -> f32
+template <int FMT>
+__device__ __forceinline__ f32x4 widen4(uint2 h, uint2 l) {
+  if constexpr (FMT == RSA_PF_F16) {
+    const f16x2 h0 = __builtin_bit_cast(f16x2, h.x), h1 = __builtin_bit_cast(f16x2, h.y);
+    const f16x2 l0 = __builtin_bit_cast(f16x2, l.x), l1 = __builtin_bit_cast(f16x2, l.y);
+    return (f32x4){(float)h0[0] + (float)l0[0], (float)h0[1] + (float)l0[1], (float)h1[0] + (float)l1[0], (float)h1[1] + (float)l1[1]};
+  } else {
+    return (f32x4){__builtin_bit_cast(float, h.x << 16) + __builtin_bit_cast(float, l.x << 16),
+                   __builtin_bit_cast(float, h.x & 0xffff0000u) + __builtin_bit_cast(float, l.x & 0xffff0000u),
+                   __builtin_bit_cast(float, h.y << 16) + __builtin_bit_cast(float, l.y << 16),
+                   __builtin_bit_cast(float, h.y & 0xffff0000u) + __builtin_bit_cast(float, l.y & 0xffff0000u)};
+  }
 }
 
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
@@ -111,12 +152,13 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 // Two D fragments of the pixel-tile pair (2k, 2k+1) of one 16-channel tile -> the 16-byte plane units of plane 2*ct + (lg >> 1):
 // the even lane group ends up with the full unit of token tile 2k, the odd one with that of 2k+1 (v_permlane16_swap, as the
 // convolution epilogue).  Returns the token tile this lane stores.
+template <int FMT = 0>
 __device__ __forceinline__ void pair_units(const f32x4 a, const f32x4 b, uint4& uh, uint4& ul) {
   uint32_t h[2][2], l[2][2];
-  split2(a[0], a[1], h[0][0], l[0][0]);
-  split2(a[2], a[3], h[0][1], l[0][1]);
-  split2(b[0], b[1], h[1][0], l[1][0]);
-  split2(b[2], b[3], h[1][1], l[1][1]);
+  split2<FMT>(a[0], a[1], h[0][0], l[0][0]);
+  split2<FMT>(a[2], a[3], h[0][1], l[0][1]);
+  split2<FMT>(b[0], b[1], h[1][0], l[1][0]);
+  split2<FMT>(b[2], b[3], h[1][1], l[1][1]);
   const u32x2 h0 = __builtin_amdgcn_permlane16_swap(h[0][0], h[1][0], false, false);
   const u32x2 h1 = __builtin_amdgcn_permlane16_swap(h[0][1], h[1][1], false, false);
   const u32x2 l0 = __builtin_amdgcn_permlane16_swap(l[0][0], l[1][0], false, false);
@@ -160,7 +202,9 @@ struct GeoLW {
 // shapes that make up an RRDBNet frame are compiled again with those tests folded:
 //   EM 1: split-plane output only (hi and lo), no residual, no f32 map, no PReLU      -- the growth convolutions (276 of 351 launches)
 //   EM 2: EM 1 + residual 1 as split planes (hi + lo) and an optional residual 2 as split planes -- conv5 of a residual dense block
-template <int NCT, int CTW, int NPT, int OUTK, int AC, int EM = 0>
+// PF = plane format of the outputs and residuals of EM 1 / 2 (the generic body reads p.out_fmt / p.res_fmt).  With PF = fp16, EM 1
+// writes hi ONLY (the one-product consumers never read lo); EM 2 keeps hi + lo (the residual stream: 22 bits).
+template <int NCT, int CTW, int NPT, int OUTK, int AC, int EM = 0, int PF = 0>
 __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f32x4 (&acc)[NPT][CTW], int n, int y0, int x0, int slab, int wct,
                                               int wpx, int li, int lg) {
   constexpr int RPW = NPT / 2;
@@ -169,7 +213,9 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
   const bool R1P = G ? p.res1_hi != nullptr : EM == 2, R2P = G ? p.res2_hi != nullptr : (EM == 2 && p.res2_hi != nullptr);  // as planes
   const bool R1L = G ? p.res1_lo != nullptr : true, R2L = G ? p.res2_lo != nullptr : true;       // ... with lo planes
   const bool OF32 = G && p.out_f32 != nullptr;
-  const bool OHI = G ? p.out_hi != nullptr : true, OLO = G ? p.out_lo != nullptr : true;
+  const bool OHI = G ? p.out_hi != nullptr : true, OLO = G ? p.out_lo != nullptr : !(EM == 1 && PF == RSA_PF_F16);
+  const bool OF16 = G ? p.out_fmt == RSA_PF_F16 : PF == RSA_PF_F16;  // plane format of the outputs / of the plane residuals
+  const bool RF16 = G ? p.res_fmt == RSA_PF_F16 : PF == RSA_PF_F16;
   const bool PRELU = G && p.act == RSA_ACT_PRELU;
   const float lin_slope = p.act == RSA_ACT_NONE ? 1.f : p.act_param;  // EM 1 / 2: act(v) = max(v, v * slope)
 #ifdef RSA_ABL_NOEPI
@@ -220,12 +266,7 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
   // as two 8-byte halves of a unit (this lane's 4 channels) and are widened to f32 here, so the arithmetic below sees one form.
   const bool has_r1 = R1F || R1P;
   const bool has_r2 = R2F || R2P;
-  auto widen = [](uint2 h, uint2 l) -> f32x4 {
-    return (f32x4){__builtin_bit_cast(float, h.x << 16) + __builtin_bit_cast(float, l.x << 16),
-                   __builtin_bit_cast(float, h.x & 0xffff0000u) + __builtin_bit_cast(float, l.x & 0xffff0000u),
-                   __builtin_bit_cast(float, h.y << 16) + __builtin_bit_cast(float, l.y << 16),
-                   __builtin_bit_cast(float, h.y & 0xffff0000u) + __builtin_bit_cast(float, l.y & 0xffff0000u)};
-  };
+  auto widen = [&](uint2 h, uint2 l) -> f32x4 { return RF16 ? widen4<RSA_PF_F16>(h, l) : widen4<RSA_PF_BF16>(h, l); };
   f32x4 nr1[2], nr2[2];
   auto fetch_res = [&](int ct, int pp) {
     const int cbase = (ctile0 + ct) * 16;
@@ -346,8 +387,8 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
           uint32_t h[2][2], l[2][2];
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
-            split2(v[e][0], v[e][1], h[e][0], l[e][0]);
-            split2(v[e][2], v[e][3], h[e][1], l[e][1]);
+            split2_rt(OF16, v[e][0], v[e][1], h[e][0], l[e][0]);
+            split2_rt(OF16, v[e][2], v[e][3], h[e][1], l[e][1]);
           }
           const int odd = lg & 1;  // odd lanes keep pixel-tile 2k+1 and give away their half of 2k; even lanes the reverse
           // v_permlane16_swap_b32 a, b swaps the odd 16-lane rows of a with the even rows of b: with a = this lane's half of pixel-tile
@@ -497,12 +538,19 @@ __device__ __forceinline__ void epilogue(const rsa_conv_params& p, const f32x4 (
       return;
     default:
 #ifndef RSA_NO_EM
-      if (OUTK == 0 && p.out_hi != nullptr && p.out_lo != nullptr && p.out_f32 == nullptr && p.res1 == nullptr && p.res2 == nullptr && p.act != RSA_ACT_PRELU &&
+      if (OUTK == 0 && p.out_hi != nullptr && p.out_f32 == nullptr && p.res1 == nullptr && p.res2 == nullptr && p.act != RSA_ACT_PRELU &&
           (p.cout & 15) == 0 && (p.act == RSA_ACT_NONE || (p.act_param >= 0.f && p.act_param <= 1.f))) {
         // the two shapes of an RRDBNet frame, with the descriptor tests folded (see EM above); wave-uniform choice
-        if (p.res1_hi == nullptr && p.res2_hi == nullptr) return epilogue_impl<NCT, CTW, NPT, OUTK, AC_LINEAR, 1>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
-        if (p.res1_hi != nullptr && p.res1_lo != nullptr && (p.res2_hi == nullptr || p.res2_lo != nullptr))
-          return epilogue_impl<NCT, CTW, NPT, OUTK, AC_LINEAR, 2>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
+        const bool planes_res = p.res1_hi != nullptr && p.res1_lo != nullptr && (p.res2_hi == nullptr || p.res2_lo != nullptr);
+        if (p.out_fmt == RSA_PF_BF16 && p.out_lo != nullptr) {
+          if (p.res1_hi == nullptr && p.res2_hi == nullptr) return epilogue_impl<NCT, CTW, NPT, OUTK, AC_LINEAR, 1>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
+          if (planes_res && p.res_fmt == RSA_PF_BF16) return epilogue_impl<NCT, CTW, NPT, OUTK, AC_LINEAR, 2>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
+        } else if (p.out_fmt == RSA_PF_F16) {
+          if (p.out_lo == nullptr && p.res1_hi == nullptr && p.res2_hi == nullptr)
+            return epilogue_impl<NCT, CTW, NPT, OUTK, AC_LINEAR, 1, RSA_PF_F16>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
+          if (p.out_lo != nullptr && planes_res && p.res_fmt == RSA_PF_F16)
+            return epilogue_impl<NCT, CTW, NPT, OUTK, AC_LINEAR, 2, RSA_PF_F16>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
+        }
       }
 #endif
       return epilogue_impl<NCT, CTW, NPT, OUTK, AC_LINEAR>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);

@@ -1,0 +1,10 @@
+// conv_inst_ring1h.hip — conv_ring<SHAPE = 1> on fp16 planes: one product (conv5 of a residual dense block under the 'auto' precision
+// policy) and three products (the trunk convolution, whose input is the fp16 residual stream).
+#include "conv_ring.h"
+
+namespace rsa {
+int conv_launch_ring1_f16(const rsa_conv_params& p, hipStream_t stream) {
+  return p.products == 1 ? launch_ring<1, 0, 0, 0, RSA_PF_F16, 1>(p, stream) : launch_ring<1, 0, 0, 0, RSA_PF_F16, 3>(p, stream);
+}
+unsigned int conv_ring1h_aborts() { return ring_aborts_this_unit(); }
+}  // namespace rsa

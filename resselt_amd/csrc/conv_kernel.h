@@ -36,7 +36,8 @@ namespace rsa {
 
 static __device__ uint4 g_zero_unit[4];  // source of zero-padding units for the loader's LDS-DMA (never written)
 
-template <int KS, int NCT, int PROD, int UP, int OUTK>
+// FMT = enum rsa_plane_fmt of the input planes and weights (the matrix instruction); fp16 is instantiated for one product only
+template <int KS, int NCT, int PROD, int UP, int OUTK, int FMT = 0>
 __global__ __launch_bounds__((GeoLW<KS, NCT>::NTHR), (GeoLW<KS, NCT>::NCW == 8 ? 3 : 2)) void conv_kernel(const rsa_conv_params p) {
   using G = GeoLW<KS, NCT>;
   constexpr int TH = G::TH, TW = G::TW, HALO = G::HALO, IH = G::IH, IW = G::IW, PS = G::PS;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__((GeoLW<KS, NCT>::NTHR), (GeoLW<KS, NCT>::NCW == 8 ?
               // products in increasing magnitude: w_lo*a_hi, w_hi*a_lo, w_hi*a_hi
               const bf16x8 wf = (PROD == 3 && pr == 0) ? wc[ct][NHL - 1] : wc[ct][0];
               const bf16x8 bf = (PROD == 3 && pr == 1) ? rl[i % (LDS_DEPTH + 1)][g] : rh[i % (LDS_DEPTH + 1)][g];
-              acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, bf, acc[pt][ct], 0, 0, 0);
+              acc[pt][ct] = mfma16<FMT>(wf, bf, acc[pt][ct]);
             }
         // issue order inside the step: the prefetch reads first, then this step's MFMAs
         if (i + LDS_DEPTH < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, NHL * GP, 0);
@@ -284,7 +285,7 @@ __global__ __launch_bounds__((GeoLW<KS, NCT>::NTHR), (GeoLW<KS, NCT>::NCW == 8 ?
   }
 }
 
-template <int KS, int NCT, int PROD, int UP, int OUTK>
+template <int KS, int NCT, int PROD, int UP, int OUTK, int FMT = 0>
 static int launch_one(const rsa_conv_params& p, hipStream_t stream) {
   using G = GeoLW<KS, NCT>;
   const int tiles_x = (p.W + G::TW - 1) / G::TW;
@@ -299,7 +300,7 @@ static int launch_one(const rsa_conv_params& p, hipStream_t stream) {
   if (resident == 0) {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_kernel<KS, NCT, PROD, UP, OUTK>, G::NTHR, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_kernel<KS, NCT, PROD, UP, OUTK, FMT>, G::NTHR, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipGetLastError();
     resident = per_cu * prop.multiProcessorCount;
     resident_cache.store(resident, std::memory_order_relaxed);
@@ -308,28 +309,28 @@ static int launch_one(const rsa_conv_params& p, hipStream_t stream) {
   int gx = resident;
   if (gx > num_tiles) gx = (int)num_tiles;
   dim3 grid((unsigned)gx, 1, 1);
-  hipLaunchKernelGGL((conv_kernel<KS, NCT, PROD, UP, OUTK>), grid, dim3(G::NTHR), 0, stream, p);
+  hipLaunchKernelGGL((conv_kernel<KS, NCT, PROD, UP, OUTK, FMT>), grid, dim3(G::NTHR), 0, stream, p);
   return (int)hipGetLastError();
 }
 
 
-template <int KS, int PROD, int UP, int OUTK>
+template <int KS, int PROD, int UP, int OUTK, int FMT = 0>
 static int launch_nct2(const rsa_conv_params& p, int nct, hipStream_t stream) {
   switch (nct) {
     case 1:
-      return launch_one<KS, 1, PROD, UP, OUTK>(p, stream);
+      return launch_one<KS, 1, PROD, UP, OUTK, FMT>(p, stream);
     case 2:
-      return launch_one<KS, 2, PROD, UP, OUTK>(p, stream);
+      return launch_one<KS, 2, PROD, UP, OUTK, FMT>(p, stream);
     case 3:
-      return launch_one<KS, 3, PROD, UP, OUTK>(p, stream);
+      return launch_one<KS, 3, PROD, UP, OUTK, FMT>(p, stream);
     default:
-      return launch_one<KS, 4, PROD, UP, OUTK>(p, stream);
+      return launch_one<KS, 4, PROD, UP, OUTK, FMT>(p, stream);
   }
 }
 
-template <int KS, int PROD, int UP>
+template <int KS, int PROD, int UP, int FMT = 0>
 static int launch_nct(const rsa_conv_params& p, int nct, hipStream_t stream) {
-  return p.out_nchw != nullptr ? launch_nct2<KS, PROD, UP, 1>(p, nct, stream) : launch_nct2<KS, PROD, UP, 0>(p, nct, stream);
+  return p.out_nchw != nullptr ? launch_nct2<KS, PROD, UP, 1, FMT>(p, nct, stream) : launch_nct2<KS, PROD, UP, 0, FMT>(p, nct, stream);
 }
 
 }  // namespace rsa

@@ -4,7 +4,10 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <stdio.h>
+
 #include <atomic>
+#include <mutex>
 
 #include "common.h"
 #include "resselt_amd.h"
@@ -16,8 +19,52 @@ int conv_launch_k3p3u0(const rsa_conv_params& p, int nct, hipStream_t stream);
 int conv_launch_k3p3u1(const rsa_conv_params& p, int nct, hipStream_t stream);
 int conv_launch_k3p1u0(const rsa_conv_params& p, int nct, hipStream_t stream);
 int conv_launch_k3p1u1(const rsa_conv_params& p, int nct, hipStream_t stream);
+int conv_launch_k3p1u0_f16(const rsa_conv_params& p, int nct, hipStream_t stream);
+int conv_launch_k3p1u1_f16(const rsa_conv_params& p, int nct, hipStream_t stream);
+int conv_launch_k1p1_f16(const rsa_conv_params& p, int nct, hipStream_t stream);
 int conv_launch_k1p3(const rsa_conv_params& p, int nct, hipStream_t stream);
 int conv_launch_k1p1(const rsa_conv_params& p, int nct, hipStream_t stream);
+
+// ---- failure word of the ring kernels: one pinned, device-mapped word per process, allocated at the first ring launch ----
+static std::atomic<unsigned int*> g_fail_host{nullptr};
+static std::atomic<unsigned int*> g_fail_dev{nullptr};
+static std::atomic<int> g_spin_limit{1 << 18};
+RingAux ring_aux() {
+  unsigned int* dev = g_fail_dev.load(std::memory_order_acquire);
+  if (dev == nullptr) {
+    static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    dev = g_fail_dev.load(std::memory_order_acquire);
+    if (dev == nullptr) {
+      unsigned int* host = nullptr;
+      void* d = nullptr;
+      if (hipHostMalloc((void**)&host, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && host != nullptr) {
+        *host = 0u;
+        if (hipHostGetDevicePointer(&d, host, 0) == hipSuccess && d != nullptr) {
+          g_fail_host.store(host, std::memory_order_release);
+          dev = (unsigned int*)d;
+          g_fail_dev.store(dev, std::memory_order_release);
+        }
+      }
+      (void)hipGetLastError();  // without the word the kernels still count into g_ring_aborts (rsa_debug_ring_aborts)
+    }
+  }
+  return RingAux{dev, g_spin_limit.load(std::memory_order_relaxed)};
+}
+void conv_set_ring_spin_limit(int polls) { g_spin_limit.store(polls < 1 ? 1 : polls, std::memory_order_relaxed); }
+int conv_check_status() {
+  unsigned int* host = g_fail_host.load(std::memory_order_acquire);
+  if (host == nullptr) return RSA_OK;
+  const unsigned int n = __atomic_exchange_n(host, 0u, __ATOMIC_ACQ_REL);
+  if (n == 0) return RSA_OK;
+  char msg[160];
+  snprintf(msg, sizeof(msg), "ring schedule: %u hand-off(s) between loader and compute waves timed out; the affected launches produced wrong pixels", n);
+  return set_error(RSA_E_INTERNAL, msg);
+}
+static bool conv_failure_pending() {
+  unsigned int* host = g_fail_host.load(std::memory_order_acquire);
+  return host != nullptr && __atomic_load_n(host, __ATOMIC_ACQUIRE) != 0;
+}
 
 static std::atomic<int> g_ring_override{-1};  // rsa_debug_set_ring: -1 = follow the environment, 0 / 1 = forced (in-process A/B runs)
 void conv_ring_override(int v) { g_ring_override.store(v < 0 ? -1 : (v ? 1 : 0)); }
@@ -42,6 +89,9 @@ const char* conv_kernel_name(const rsa_conv_params& p) {
   if (p.w_layout == RSA_WL_UPPHASE) return "rsa::conv_ring_up2 (x2 upsampling as four 2x2 phases)";
   if (p.w_layout != RSA_WL_TAPS) {
     const int ct = (p.cout + 15) >> 4;
+    if (p.products == 1)
+      return ct == 2 ? "rsa::conv_ring<2,0,0,0,f16,1> (Cout<=32, one fp16 product)" : ct == 3 ? (p.out_nchw != nullptr ? "rsa::conv_ring<3,0,1,HM,f16,1> (Cout 33..48, final store, one fp16 product)" : "rsa::conv_ring<3,0,0,HM,f16,1> (Cout 33..48, one fp16 product)") : "rsa::conv_ring<1,0,0,0,f16,1> (Cout 49..64, one fp16 product)";
+    if (p.in_fmt == RSA_PF_F16) return "rsa::conv_ring<1,0,0,0,f16,3> (Cout 49..64, three fp16 products)";
     return ct == 2 ? "rsa::conv_ring<2,UP,0> (Cout<=32)" : ct == 3 ? (p.out_nchw != nullptr ? "rsa::conv_ring<3,0,1,HM> (Cout 33..48, final store)" : "rsa::conv_ring<3,0,0,HM> (Cout 33..48)") : "rsa::conv_ring<1,UP,0> (Cout 49..64)";
   }
   if (p.ksize == 1 && p.cout >= 96 && p.out_nchw == nullptr) return "rsa::gemm_k1_kernel";
@@ -62,6 +112,9 @@ int conv_launch(const rsa_conv_params& p, hipStream_t stream) {
   if (p.batch < 1 || p.H < 1 || p.W < 1 || p.cin_planes < 1 || p.cout < 1) return set_error(RSA_E_ARG, "conv: bad geometry");
   if (p.ksize != 1 && p.ksize != 3) return set_error(RSA_E_UNSUPPORTED, "conv: ksize must be 1 or 3");
   if (p.products != 1 && p.products != 3) return set_error(RSA_E_UNSUPPORTED, "conv: products must be 1 or 3");
+  if ((unsigned)p.in_fmt > RSA_PF_F16 || (unsigned)p.out_fmt > RSA_PF_F16 || (unsigned)p.res_fmt > RSA_PF_F16 || p.reserved0 != 0)
+    return set_error(RSA_E_ARG, "conv: in_fmt / out_fmt / res_fmt must be an rsa_plane_fmt, reserved0 zero");
+  if (conv_failure_pending()) return set_error(RSA_E_INTERNAL, "conv: an earlier ring-schedule launch reported a failed hand-off; call rsa_check_status()");
   if (p.upsample2x && (p.ksize != 3 || (p.H & 1) || (p.W & 1))) return set_error(RSA_E_UNSUPPORTED, "conv: upsample2x needs k3 and even H, W");
   if (p.in_hi == nullptr || p.w_packed == nullptr) return set_error(RSA_E_ARG, "conv: null input/weights");
   if (p.products == 3 && p.in_lo == nullptr) return set_error(RSA_E_ARG, "conv: products=3 needs in_lo");
@@ -101,19 +154,22 @@ int conv_launch(const rsa_conv_params& p, hipStream_t stream) {
     const int rc = conv_launch_ring(p, stream);
     return rc ? set_error(rc, "conv: ring kernel launch failed") : RSA_OK;
   }
+  if (p.in_fmt == RSA_PF_F16 && p.products == 3)
+    return set_error(RSA_E_UNSUPPORTED, "conv: three fp16 products exist for 3x3 layers with whole 32-channel chunks and 49..64 output channels only");
   if (p.ksize == 1) {  // wide k1 layers (nn.Linear over tokens): weight-stationary GEMM schedule, gemm_k1.hip
     const int g = gemm_k1_launch(p, stream);
     if (g != -100) return g == 0 ? RSA_OK : set_error(g, "conv: gemm_k1 launch failed");
   }
   const int nct = conv_nct(p.cout);
+  const bool f16 = p.in_fmt == RSA_PF_F16;  // one product here
   int rc;
   if (p.ksize == 3) {
     if (p.upsample2x)
-      rc = (p.products == 3) ? conv_launch_k3p3u1(p, nct, stream) : conv_launch_k3p1u1(p, nct, stream);
+      rc = (p.products == 3) ? conv_launch_k3p3u1(p, nct, stream) : f16 ? conv_launch_k3p1u1_f16(p, nct, stream) : conv_launch_k3p1u1(p, nct, stream);
     else
-      rc = (p.products == 3) ? conv_launch_k3p3u0(p, nct, stream) : conv_launch_k3p1u0(p, nct, stream);
+      rc = (p.products == 3) ? conv_launch_k3p3u0(p, nct, stream) : f16 ? conv_launch_k3p1u0_f16(p, nct, stream) : conv_launch_k3p1u0(p, nct, stream);
   } else {
-    rc = (p.products == 3) ? conv_launch_k1p3(p, nct, stream) : conv_launch_k1p1(p, nct, stream);
+    rc = (p.products == 3) ? conv_launch_k1p3(p, nct, stream) : f16 ? conv_launch_k1p1_f16(p, nct, stream) : conv_launch_k1p1(p, nct, stream);
   }
   if (rc != 0) return set_error(rc, "conv: kernel launch failed");
   return RSA_OK;

@@ -1,4 +1,4 @@
-// conv_ring.h — ring schedule of the fused 3x3 convolution (split-bf16, three products) for layers whose input is a whole number of
+// conv_ring.h — ring schedule of the fused 3x3 convolution (three products on split planes, or ONE product on hi planes) for layers whose input is a whole number of
 // 16-channel half chunks and that have 17..64 output channels: every convolution of a residual dense block (utilities/block.py:454-465
 // of the reference: 64/96/128/160 -> 32 and 192 -> 64), the trunk / upsampling / HR convolutions of RRDBNet (archs/esrgan/arch.py:82-118),
 // the 48 -> 48 re-parameterised convolutions of SPAN / SPANPlus / SpanPP (archs/spanplus/arch.py:94-130; 1.5 chunks: the trailing half
@@ -21,6 +21,11 @@
 //   * tiles are ordered in bands of four tile rows, column-major inside a band, so that the 32 consecutive tiles an XCD works on at
 //     any time form a 4 x 8 block: the halo rows shared with the tile above / below are L2 hits instead of a second HBM fetch.
 //
+// One-product mode (PROD 1, round 3: the fp16 layers of the 'auto' precision policy).  A slot holds hi planes only (19.5 KB), so the ring has
+// EIGHT slots (four per stream in SHAPE 2); the loader keeps two fills in flight behind the one it publishes; a K step is a third as long, so
+// the weight fragments are requested two K steps ahead and the LDS fragments four pixel-tile steps ahead.  FMT selects the matrix instruction
+// (v_mfma_f32_16x16x32_bf16 / _f16); it is orthogonal to PROD (the trunk convolution of RRDBNet runs three fp16 products).
+//
 // Three shapes:  SHAPE 2 (Cout <= 32): waves 0-3 / 4-7 are two independent streams, each with its own tiles, two ring slots
 // and loader wave (8 / 9); a wave owns 4 rows x 32 pixels x 2 cout tiles, so each activation fragment read from LDS feeds both
 // cout tiles.  SHAPE 1 (Cout 49..64): eight waves = 2 cout groups x 4 row groups on one tile stream over all four slots.
@@ -31,10 +36,6 @@
 
 #include "conv_common.h"
 #include "conv_kernel.h"
-
-#ifndef RSA_RING_SPIN_LIMIT
-#define RSA_RING_SPIN_LIMIT (1 << 18)
-#endif
 
 namespace rsa {
 
@@ -48,8 +49,9 @@ static __device__ unsigned int g_ring_dbg;
 #define RING_DBG(bit) false
 #endif
 
-static __device__ unsigned int g_ring_aborts;  // spins that ran into RSA_RING_SPIN_LIMIT (a protocol bug): never non-zero in a correct build
+static __device__ unsigned int g_ring_aborts;  // spins that ran into their bound (a protocol bug): never non-zero in a correct build
 // (one counter per translation unit that instantiates the schedule; conv_ring_aborts() adds them up)
+
 static unsigned int ring_aborts_this_unit() {
   unsigned int v = 0;
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ring_aborts), sizeof(v)) != hipSuccess) return 0x10000000u;
@@ -58,15 +60,21 @@ static unsigned int ring_aborts_this_unit() {
 
 typedef const __attribute__((address_space(1))) char* gcptr;
 
-struct RingGeo {
+template <int PROD>
+struct RingGeoP {
   static constexpr int TH = 16, TW = 32, IH = 18, IW = 34;
   static constexpr int PS = 624;             // plane stride in units (IH*IW = 612 rounded up to 0 mod 16)
   static constexpr int HALF = 2 * PS;        // units of one precision of a slot (2 planes)
-  static constexpr int SLOT = 2 * HALF;      // units per slot: [hi p0][hi p1][lo p0][lo p1]
-  static constexpr int NSLOT = 4;
+  static constexpr int NHL = PROD == 3 ? 2 : 1;
+  static constexpr int SLOT = NHL * HALF;    // units per slot: [hi p0][hi p1]([lo p0][lo p1])
+  static constexpr int NSLOT = PROD == 3 ? 4 : 8;
   static constexpr int DMA_IT = (HALF + 63) / 64;  // 20 LDS-DMA instructions per precision; the last one covers 32 units
+  static constexpr int DPF = NHL * DMA_IT;   // LDS-DMA instructions per fill
+  static constexpr int INFL = PROD == 3 ? 1 : 2;  // fills left in flight behind the one being published (INFL * DPF <= 63: vmcnt)
   static constexpr int BAND = 4;             // tile rows per band of the tile order
+  static constexpr int FLAG_UNITS = 5;       // uint4s behind the ring: FULL[8], FREE[8], abort
 };
+using RingGeo = RingGeoP<3>;
 
 // tile index (band order) -> image, tile row, tile column
 __device__ __forceinline__ void ring_tile_coords(int t, int tiles_x, int tiles_y, int& n, int& ty, int& tx) {
@@ -85,17 +93,22 @@ __device__ __forceinline__ uint32_t lds_ld(const uint32_t* p) { return __hip_ato
 // Wait until *flag >= need.  The spin is bounded: when it runs out (a protocol bug), or a sibling wave's has, the abort word is
 // set and the wait returns anyway -- every later wait of the workgroup then returns after at most 64 polls, so the kernel always
 // drains (with wrong results, and g_ring_aborts != 0 to say so) instead of hanging the GPU.
-__device__ __forceinline__ void ring_wait_slow(const uint32_t* flag, uint32_t need, uint32_t* abort_word) {
-  for (int spin = 0; spin < RSA_RING_SPIN_LIMIT; ++spin) {
+__device__ __forceinline__ void ring_wait_slow(const uint32_t* flag, uint32_t need, uint32_t* abort_word, const RingAux& aux) {
+  const int limit = __builtin_amdgcn_readfirstlane(aux.spin_limit);
+  for (int spin = 0; spin < limit; ++spin) {
     __builtin_amdgcn_s_sleep(1);
     if (__builtin_amdgcn_readfirstlane(lds_ld(flag)) >= need) return;
     if ((spin & 63) == 63 && __builtin_amdgcn_readfirstlane(lds_ld(abort_word)) != 0) return;
   }
   __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  if ((threadIdx.x & 63) == 0) atomicAdd(&g_ring_aborts, 1u);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&g_ring_aborts, 1u);
+    // the host-visible word (pinned, mapped): rsa_check_status() turns it into RSA_E_INTERNAL without synchronising anything
+    if (aux.fail_word != nullptr) __hip_atomic_fetch_add(aux.fail_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
-__device__ __forceinline__ void ring_wait(const uint32_t* flag, uint32_t need, uint32_t* abort_word) {
-  if (__builtin_expect(__builtin_amdgcn_readfirstlane(lds_ld(flag)) < need, 0)) ring_wait_slow(flag, need, abort_word);
+__device__ __forceinline__ void ring_wait(const uint32_t* flag, uint32_t need, uint32_t* abort_word, const RingAux& aux) {
+  if (__builtin_expect(__builtin_amdgcn_readfirstlane(lds_ld(flag)) < need, 0)) ring_wait_slow(flag, need, abort_word, aux);
 }
 
 __device__ __forceinline__ gcptr uniform_ptr(gcptr q) {  // tell the compiler a pointer is wave-uniform (an SGPR pair)
@@ -118,24 +131,26 @@ __device__ __forceinline__ void dma16_v(uint32_t lds_addr, gcptr vaddr) {
 // chunks: 48 input channels = 3): the unit is one half chunk, five K steps -- four tap pairs and a step in which only lane groups
 // 0-1 carry tap (2,2) (the other two multiply zero weights); 15 K steps for 48 channels where whole chunks would need 18.  A second
 // kernel rather than a second loop body: two unrolled bodies in one kernel spill hundreds of registers.
-template <int SHAPE, int UP, int OUTK, int HM = 0>
-__global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(const rsa_conv_params p) {
-  using R = RingGeo;
+// FMT: enum rsa_plane_fmt of the input planes and weights.  PROD: 3 = hi*hi + lo*hi + hi*lo on split planes, 1 = hi*hi on hi planes.
+template <int SHAPE, int UP, int OUTK, int HM = 0, int FMT = 0, int PROD = 3>
+__global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(const rsa_conv_params p, const RingAux aux) {
+  using R = RingGeoP<PROD>;
   constexpr int STREAMS = SHAPE == 2 ? 2 : 1;
   constexpr int TH = R::TH, TW = R::TW, IH = R::IH, IW = R::IW, PS = R::PS, HALF = R::HALF, SLOT = R::SLOT, NSLOT = R::NSLOT;
+  constexpr int NHL = R::NHL, INFL = R::INFL;
   constexpr int NCT = SHAPE == 2 ? 2 : (SHAPE == 1 ? 4 : 3);  // cout tiles of the layer handled by one workgroup
   constexpr int CTW = SHAPE == 3 ? 3 : 2;       // cout tiles per wave
   constexpr int NPT = SHAPE == 3 ? 4 : 8;       // pixel tiles per wave (RPW rows x 2 halves)
   constexpr int RPW = NPT / 2;
   constexpr int NCONS = (STREAMS == 2) ? 4 : 8; // consumer waves per slot
-  constexpr int SPS = NSLOT / STREAMS;          // slots per stream
+  constexpr int SPS = NSLOT / STREAMS;          // slots per stream (a power of two)
 
   // ring + flags in ONE shared array (a second __shared__ object can make hipcc drain vmcnt before LDS reads)
-  __shared__ uint4 s_ring[NSLOT * SLOT + 4];
-  uint32_t* const flags = (uint32_t*)&s_ring[NSLOT * SLOT];  // [0..3] FULL, [4..7] FREE, [8] abort
+  __shared__ uint4 s_ring[NSLOT * SLOT + R::FLAG_UNITS];
+  uint32_t* const flags = (uint32_t*)&s_ring[NSLOT * SLOT];  // [0..7] FULL, [8..15] FREE, [16] abort
   uint32_t* const f_full = flags;
-  uint32_t* const f_free = flags + 4;
-  uint32_t* const f_abort = flags + 8;
+  uint32_t* const f_free = flags + 8;
+  uint32_t* const f_abort = flags + 16;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -153,7 +168,7 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
   if (tile0 >= num_tiles) return;  // whole workgroup
   const int ntw = (num_tiles - tile0 + NWG - 1) / NWG;  // tiles of this workgroup: tile0 + j*NWG
 
-  if (tid < 16) flags[tid] = 0;
+  if (tid < 4 * R::FLAG_UNITS) flags[tid] = 0;
   __syncthreads();  // the only workgroup barrier of the kernel
 #ifdef RSA_RING_DEBUG
   const unsigned dbg = __builtin_amdgcn_readfirstlane(g_ring_dbg);
@@ -184,8 +199,19 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
     }
     const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)s_ring;
     int k = 0;                      // half-chunk counter of this stream
-    int pend_slot = -1;             // fill issued but not yet published
-    uint32_t pend_val = 0;
+    // fills issued but not yet published, oldest first: pend[0] is published once everything but the INFL youngest fills has landed
+    int pend_slot[INFL];
+    uint32_t pend_val[INFL];
+#pragma unroll
+    for (int i = 0; i < INFL; ++i) pend_slot[i] = -1, pend_val[i] = 0;
+    auto publish_all = [&]() {  // before blocking, and at the end: the consumers may need these fills to get to the release the loader waits for
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < INFL; ++i) {
+        if (pend_slot[i] >= 0) __hip_atomic_store(&f_full[pend_slot[i]], pend_val[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        pend_slot[i] = -1;
+      }
+    };
     for (int j = (STREAMS == 2 ? g : 0); j < ntw; j += STREAMS) {
       int n, ty, tx;
       ring_tile_coords(tile0 + j * NWG, tiles_x, tiles_y, n, ty, tx);
@@ -194,16 +220,15 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
       // source unit of the halo origin in plane 0 of this image (used by interior tiles only, where it is inside the map)
       const int64_t tile_unit = (int64_t)n * p.in_batch_stride + (int64_t)(UP ? ty * (TH / 2) - 1 : y0) * inW + (UP ? tx * (TW / 2) - 1 : x0);
       for (int h = 0; h < nhalf; ++h, ++k) {
-        const int slot = (STREAMS == 2) ? 2 * g + (k & 1) : (k & 3);
+        const int slot = (STREAMS == 2) ? SPS * g + (k & (SPS - 1)) : (k & (NSLOT - 1));
         const uint32_t use = (uint32_t)(k / SPS);  // how many times this slot has been filled before
         // the slot must have been released by all its consumers `use` times
         if (__builtin_amdgcn_readfirstlane(lds_ld(&f_free[slot])) < NCONS * use) {
-          if (pend_slot >= 0) {  // publish what has been issued before blocking: the consumers may need it to get here
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&f_full[pend_slot], pend_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            pend_slot = -1;
-          }
-          ring_wait(&f_free[slot], NCONS * use, f_abort);
+          bool any = false;
+#pragma unroll
+          for (int i = 0; i < INFL; ++i) any = any || pend_slot[i] >= 0;
+          if (any) publish_all();
+          ring_wait(&f_free[slot], NCONS * use, f_abort, aux);
         }
         const int64_t half_unit = tile_unit + (int64_t)(2 * h) * p.in_plane_stride;  // first plane of this half chunk
         gcptr bh = uniform_ptr((gcptr)p.in_hi + half_unit * 16);
@@ -215,7 +240,7 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
           for (int it = 0; it < R::DMA_IT; ++it) {
             if (it == R::DMA_IT - 1 && lane >= 32) continue;  // the last instruction of a precision covers 32 units (EXEC-masked)
             dma16_s(dst + it * 1024, lc[it], bh);
-            dma16_s(dst + HALF * 16 + it * 1024, lc[it], bl);
+            if (PROD == 3) dma16_s(dst + HALF * 16 + it * 1024, lc[it], bl);
           }
         } else {
 #pragma unroll
@@ -231,24 +256,25 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
             }
             const int64_t off = ((int64_t)n * p.in_batch_stride + (int64_t)(2 * h + pl) * p.in_plane_stride + (int64_t)iy * inW + ix) * 16;
             gcptr sh = ok ? (gcptr)p.in_hi + off : (gcptr)&g_zero_unit[0];
-            gcptr sl = ok ? (gcptr)p.in_lo + off : (gcptr)&g_zero_unit[0];
             dma16_v(dst + it * 1024, sh);
-            dma16_v(dst + HALF * 16 + it * 1024, sl);
+            if (PROD == 3) {
+              gcptr sl = ok ? (gcptr)p.in_lo + off : (gcptr)&g_zero_unit[0];
+              dma16_v(dst + HALF * 16 + it * 1024, sl);
+            }
           }
         }
-        if (pend_slot >= 0) {
-          // everything but the 2*DMA_IT instructions just issued has landed: publish the previous fill
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * R::DMA_IT) : "memory");
-          __hip_atomic_store(&f_full[pend_slot], pend_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (pend_slot[0] >= 0) {
+          // everything but the INFL fills issued last (this one included) has landed: publish the oldest pending fill
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL * R::DPF) : "memory");
+          __hip_atomic_store(&f_full[pend_slot[0]], pend_val[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        pend_slot = slot;
-        pend_val = use + 1;
+#pragma unroll
+        for (int i = 0; i + 1 < INFL; ++i) pend_slot[i] = pend_slot[i + 1], pend_val[i] = pend_val[i + 1];
+        pend_slot[INFL - 1] = slot;
+        pend_val[INFL - 1] = use + 1;
       }
     }
-    if (pend_slot >= 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(&f_full[pend_slot], pend_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    publish_all();
     return;
   }
 
@@ -260,27 +286,36 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
   const int lg = lane >> 4;
   const int hsel = lg >> 1;  // which tap of a pair / which half in the pairing step
 
-  // weights: per (chunk, K step 0..8, cout tile, hi|lo) one 1 KiB A fragment, streamed from L2 one K step ahead
+  // weights: per (chunk, K step 0..8, cout tile, hi|lo) one 1 KiB A fragment, streamed from L2 WD K steps ahead
   constexpr int KSU = HM ? 5 : 9;  // K steps per unit
+  constexpr int WD = PROD == 3 ? 1 : 2;  // K steps of weight prefetch (a one-product K step is 16 MFMAs = 256 cycles: less than an L2 hit under load)
   const int nks = nq * KSU;
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_packed, 0, (uint32_t)((int64_t)nks * ct_total * 2 * 64 * 16), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_packed, 0, (uint32_t)((int64_t)nks * ct_total * NHL * 64 * 16), 0x00020000);
   uint32_t woff[CTW];
 #pragma unroll
   for (int c = 0; c < CTW; ++c) {
     const int ctg = wct * CTW + c;
-    woff[c] = (ctg < ct_total) ? (uint32_t)((ctg * 2 * 64 + lane) * 16) : 0xFFFFFFFFu;  // out of range -> zeros
+    woff[c] = (ctg < ct_total) ? (uint32_t)((ctg * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;  // out of range -> zeros
   }
-  const uint32_t wstep = (uint32_t)ct_total * 2 * 64 * 16;
-  bf16x8 wc[CTW][2], wn[CTW][2];
-  auto load_w = [&](int s) {
+  const uint32_t wstep = (uint32_t)ct_total * NHL * 64 * 16;
+  bf16x8 wq[WD + 1][CTW][NHL];  // wq[0]: the K step being multiplied; wq[1..WD]: the next ones, in flight
+  auto load_w = [&](int s) {    // -> wq[WD]
 #pragma unroll
     for (int c = 0; c < CTW; ++c)
 #pragma unroll
-      for (int hl = 0; hl < 2; ++hl) {
+      for (int hl = 0; hl < NHL; ++hl) {
         if (RING_DBG(4)) continue;
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, woff[c], (uint32_t)s * wstep + (uint32_t)hl * 1024u, 0);
-        wn[c][hl] = __builtin_bit_cast(bf16x8, v);
+        wq[WD][c][hl] = __builtin_bit_cast(bf16x8, v);
       }
+  };
+  auto shift_w = [&]() {
+#pragma unroll
+    for (int d = 0; d < WD; ++d)
+#pragma unroll
+      for (int c = 0; c < CTW; ++c)
+#pragma unroll
+        for (int hl = 0; hl < NHL; ++hl) wq[d][c][hl] = wq[d + 1][c][hl];
   };
 
   f32x4 acc[NPT][CTW];
@@ -295,12 +330,10 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
   const int lane_u = (lg & 1) * PS + (wpx * RPW) * IW + li;
   int uA1, uA2, uB1, uB2, uS;  // set per chunk from the slots it lives in
 
-  // De-phase the two waves that share a SIMD (waves w and w + 4), so that one's epilogue (vector ALU + stores, no matrix work) lies
-  // beside the other's multiply instead of both storing at once with the matrix pipes idle:
-  //   STREAMS == 2: the streams are independent; stream 1 starts about half a tile late (the offset then persists);
-  //   STREAMS == 1: waves 4-7 get the lower priority, fall behind by as much as the ring allows (two chunks) and stay there.
+  // De-phasing of the two waves that share a SIMD (stream 1 half a tile late / a lower priority for waves 0-3) measured +-0 on the
+  // three-product kernels (profiles/r02_c): off unless a variant build asks for it.
 #ifndef RSA_RING_STAGGER
-#define RSA_RING_STAGGER 1
+#define RSA_RING_STAGGER 0
 #endif
   if (RSA_RING_STAGGER) {
     if (STREAMS == 2) {
@@ -311,10 +344,22 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
     }
   }
 
-  load_w(0);
+  // the first WD K steps' weights (steps wrap around: every tile of the layer reads the same blob)
+#pragma unroll
+  for (int d = 0; d < WD; ++d) {
+    load_w(d < nks ? d : 0);
+    if (d + 1 < WD) {  // rotate so that step d sits in wq[d + 1] once all WD are issued
+#pragma unroll
+      for (int e = 1; e < WD; ++e)
+#pragma unroll
+        for (int c = 0; c < CTW; ++c)
+#pragma unroll
+          for (int hl = 0; hl < NHL; ++hl) wq[e][c][hl] = wq[e + 1][c][hl];
+    }
+  }
   uint32_t kc = 0;  // half chunks this stream has consumed: half chunk k lives in slot slot_of(k), which it is the use_of(k)-th to use
-  auto slot_of = [&](uint32_t k) -> int { return (STREAMS == 2) ? 2 * g + (int)(k & 1) : (int)(k & 3); };
-  auto use_of = [&](uint32_t k) -> uint32_t { return (STREAMS == 2) ? (k >> 1) : (k >> 2); };
+  auto slot_of = [&](uint32_t k) -> int { return (STREAMS == 2) ? SPS * g + (int)(k & (SPS - 1)) : (int)(k & (NSLOT - 1)); };
+  auto use_of = [&](uint32_t k) -> uint32_t { return k / SPS; };
   for (int j = (STREAMS == 2 ? g : 0); j < ntw; j += STREAMS) {
     for (int c = 0; c < nq; ++c) {
       const int sA = slot_of(kc), sB = HM ? sA : slot_of(kc + 1);
@@ -329,13 +374,13 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
         // again and multiply zero weights (finite data: 0 * finite = 0)
         uS = (hsel ? bB : bA) + 2 * IW + 2;
       }
-      ring_wait(&f_full[sA], needA, f_abort);
+      ring_wait(&f_full[sA], needA, f_abort, aux);
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("" ::: "memory");
 
       constexpr int NSTEP = KSU * NPT;  // K steps x pixel tiles of one unit
-      constexpr int DEPTH = 2;
-      bf16x8 rh[DEPTH + 1], rl[DEPTH + 1];
+      constexpr int DEPTH = PROD == 3 ? 2 : 4;  // pixel-tile steps of LDS prefetch (a one-product step is CTW MFMAs = 32-48 cycles)
+      bf16x8 rh[DEPTH + 1], rl[PROD == 3 ? DEPTH + 1 : 1];
       auto frag = [&](int i) -> int {  // unit of pixel-tile step i (compile-time i)
         const int ks = i / NPT, pt = i % NPT;
         const int ptoff = (pt >> 1) * IW + (pt & 1) * 16;
@@ -354,18 +399,15 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
 #pragma unroll
       for (int i = 0; i < DEPTH; ++i) {
         rh[i] = *(const bf16x8*)&s_ring[frag(i)];
-        rl[i] = *(const bf16x8*)&s_ring[HALF + frag(i)];
+        if (PROD == 3) rl[i] = *(const bf16x8*)&s_ring[HALF + frag(i)];
       }
       // one pixel-tile step: prefetch the fragments of step i + DEPTH, multiply step i (i is a compile-time constant after unrolling)
       auto step = [&](int i) {
         const int ks = i / NPT, sp = i % NPT;
         if (sp == 0) {
-#pragma unroll
-          for (int cc = 0; cc < CTW; ++cc)
-#pragma unroll
-            for (int hl = 0; hl < 2; ++hl) wc[cc][hl] = wn[cc][hl];
-          const int s = c * KSU + ks;
-          load_w(s + 1 < nks ? s + 1 : 0);  // next K step; after the last one: step 0 of the next tile
+          shift_w();
+          const int s = c * KSU + ks + WD;  // the K step WD ahead; past the last one: the first steps of the next tile
+          load_w(s < nks ? s : s - nks);
           if (ks == 5) {
             // every read of half A has been consumed by an MFMA (the last ones in the step before): hand the slot back to the loader
             asm volatile("" ::: "memory");
@@ -376,20 +418,20 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
         if (i + DEPTH < NSTEP && !RING_DBG(16)) {
           const int u = frag(i + DEPTH);
           rh[(i + DEPTH) % (DEPTH + 1)] = *(const bf16x8*)&s_ring[u];
-          rl[(i + DEPTH) % (DEPTH + 1)] = *(const bf16x8*)&s_ring[HALF + u];
+          if (PROD == 3) rl[(i + DEPTH) % (DEPTH + 1)] = *(const bf16x8*)&s_ring[HALF + u];
         }
         if (!RING_DBG(2))
 #pragma unroll
-        for (int pr = 0; pr < 3; ++pr)
+        for (int pr = 0; pr < PROD; ++pr)
 #pragma unroll
           for (int ct = 0; ct < CTW; ++ct) {
             // products in increasing magnitude: w_lo*a_hi, w_hi*a_lo, w_hi*a_hi
-            const bf16x8 wf = (pr == 0) ? wc[ct][1] : wc[ct][0];
-            const bf16x8 bf = (pr == 1) ? rl[i % (DEPTH + 1)] : rh[i % (DEPTH + 1)];
-            acc[sp][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, bf, acc[sp][ct], 0, 0, 0);
+            const bf16x8 wf = (PROD == 3 && pr == 0) ? wq[0][ct][NHL - 1] : wq[0][ct][0];
+            const bf16x8 bf = (PROD == 3 && pr == 1) ? rl[PROD == 3 ? i % (DEPTH + 1) : 0] : rh[i % (DEPTH + 1)];
+            acc[sp][ct] = mfma16<FMT>(wf, bf, acc[sp][ct]);
           }
-        if (i + DEPTH < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 3 * CTW, 0);
+        if (i + DEPTH < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, NHL, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, PROD * CTW, 0);
         __builtin_amdgcn_sched_barrier(0);
       };
       if (HM) {
@@ -402,7 +444,7 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
         constexpr int FIRST_B = 4 * NPT - DEPTH;  // the step whose prefetch is the first read of the pairing step (half B)
 #pragma unroll
         for (int i = 0; i < FIRST_B; ++i) step(i);
-        ring_wait(&f_full[sB], needB, f_abort);
+        ring_wait(&f_full[sB], needB, f_abort, aux);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -425,10 +467,10 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
   }
 }
 
-template <int SHAPE, int UP, int OUTK, int HM = 0>
+template <int SHAPE, int UP, int OUTK, int HM = 0, int FMT = 0, int PROD = 3>
 static int launch_ring(const rsa_conv_params& p, hipStream_t stream) {
   constexpr int STREAMS = SHAPE == 2 ? 2 : 1;
-  using R = RingGeo;
+  using R = RingGeoP<PROD>;
   const int tiles_x = (p.W + R::TW - 1) / R::TW;
   const int tiles_y = (p.H + R::TH - 1) / R::TH;
   const int64_t num_tiles = (int64_t)tiles_x * tiles_y * p.batch;
@@ -441,7 +483,7 @@ static int launch_ring(const rsa_conv_params& p, hipStream_t stream) {
   }();
   int gx = cus;  // one persistent workgroup per CU (the ring takes the whole LDS)
   if (gx > num_tiles) gx = (int)num_tiles;
-  hipLaunchKernelGGL((conv_ring<SHAPE, UP, OUTK, HM>), dim3((unsigned)gx, 1, 1), dim3((8 + STREAMS) * 64), 0, stream, p);
+  hipLaunchKernelGGL((conv_ring<SHAPE, UP, OUTK, HM, FMT, PROD>), dim3((unsigned)gx, 1, 1), dim3((8 + STREAMS) * 64), 0, stream, p, ring_aux());
   return (int)hipGetLastError();
 }
 

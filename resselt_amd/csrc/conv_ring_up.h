@@ -17,7 +17,7 @@
 
 namespace rsa {
 
-__global__ __launch_bounds__(9 * 64, 3) void conv_ring_up2(const rsa_conv_params p) {
+__global__ __launch_bounds__(9 * 64, 3) void conv_ring_up2(const rsa_conv_params p, const RingAux aux) {
   using R = RingGeo;
   constexpr int TH = R::TH, TW = R::TW, IH = R::IH, IW = R::IW, PS = R::PS, HALF = R::HALF, SLOT = R::SLOT, NSLOT = R::NSLOT;
   constexpr int NCONS = 8, NHALF = 4;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(9 * 64, 3) void conv_ring_up2(const rsa_conv_params
             __hip_atomic_store(&f_full[pend_slot], pend_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             pend_slot = -1;
           }
-          ring_wait(&f_free[slot], NCONS * use, f_abort);
+          ring_wait(&f_free[slot], NCONS * use, f_abort, aux);
         }
         const int64_t half_unit = tile_unit + (int64_t)(2 * h) * p.in_plane_stride;
         gcptr bh = uniform_ptr((gcptr)p.in_hi + half_unit * 16);
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(9 * 64, 3) void conv_ring_up2(const rsa_conv_params
     ring_tile_coords(tile0 + j * NWG, tiles_x, tiles_y, n, ty, tx);
     // the whole tile (four half chunks = the four slots) is needed by every phase: wait for it here, where no accumulator is live
 #pragma unroll
-    for (int h = 0; h < NHALF; ++h) ring_wait(&f_full[(kc + h) & 3], ((kc + h) >> 2) + 1, f_abort);
+    for (int h = 0; h < NHALF; ++h) ring_wait(&f_full[(kc + h) & 3], ((kc + h) >> 2) + 1, f_abort, aux);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
 
@@ -274,7 +274,7 @@ static int launch_ring_up2(const rsa_conv_params& p, hipStream_t stream) {
   }();
   int gx = cus;  // one persistent workgroup per CU (the ring takes the whole LDS)
   if (gx > num_tiles) gx = (int)num_tiles;
-  hipLaunchKernelGGL(conv_ring_up2, dim3((unsigned)gx, 1, 1), dim3(9 * 64), 0, stream, p);
+  hipLaunchKernelGGL(conv_ring_up2, dim3((unsigned)gx, 1, 1), dim3(9 * 64), 0, stream, p, ring_aux());
   return (int)hipGetLastError();
 }
 

@@ -287,6 +287,7 @@ static int launch_gemm(const rsa_conv_params& p, hipStream_t stream) {
 // Returns -100 when the layer is not a fit for this schedule (caller falls back to the halo-tile kernels).
 int gemm_k1_launch(const rsa_conv_params& p, hipStream_t stream) {
   if (p.ksize != 1 || p.out_nchw != nullptr || p.upsample2x) return -100;
+  if (p.in_fmt != RSA_PF_BF16 || p.out_fmt != RSA_PF_BF16) return -100;  // bf16 planes only (fp16 layers take conv_kernel<1, ...>)
   if (p.res1_hi != nullptr || p.res2_hi != nullptr) return -100;  // plane residuals: only the halo-tile kernels' epilogue reads them
   if (p.act == RSA_ACT_MISH || p.act == RSA_ACT_SILU) return -100;  // only the linear class, GELU and the SPAB gate are compiled into this schedule
   if (p.cout < 96) return -100;  // too few cout tiles to occupy 8 waves

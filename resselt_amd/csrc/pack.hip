@@ -1,5 +1,5 @@
 // pack.hip — rsa_pack_weights: OIHW f32 convolution weights -> the MFMA A-fragment blob the convolution kernels stream
-// (split bf16: hi = RNE(w), lo = RNE(w - hi)).  Replaces, on the device and behind the C-ABI, what nn.Module.load_state_dict
+// (split planes of format fmt, bf16 or fp16: hi = RNE(w), lo = RNE(w - hi)).  Replaces, on the device and behind the C-ABI, what nn.Module.load_state_dict
 // does for the reference's nn.Conv2d parameters (reference registry.py:113): the engine's kernels never see OIHW.
 //
 // One thread per (K step, cout tile, lane) writes that lane's 8-element fragment of hi (and lo).
@@ -25,7 +25,21 @@ namespace rsa {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 pk_bf16x8;
 
-__global__ void pack_weights_kernel(const float* __restrict__ w, int cout, int cin, int cin_planes, int ksize, int products, int layout, void* out) {
+// one element -> (hi, lo) halves of plane format fmt, as 16-bit patterns
+__device__ __forceinline__ void split_elem(float v, int fmt, uint16_t& hi, uint16_t& lo) {
+  if (fmt == RSA_PF_F16) {
+    const _Float16 h = (_Float16)v;
+    hi = __builtin_bit_cast(uint16_t, h);
+    lo = __builtin_bit_cast(uint16_t, (_Float16)(v - (float)h));
+  } else {
+    const __bf16 h = (__bf16)v;
+    hi = __builtin_bit_cast(uint16_t, h);
+    lo = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)h));
+  }
+}
+typedef __attribute__((ext_vector_type(8))) uint16_t pk_u16x8;
+
+__global__ void pack_weights_kernel(const float* __restrict__ w, int cout, int cin, int cin_planes, int ksize, int products, int layout, int fmt, void* out) {
   const int T = layout == RSA_WL_HALFPAIRS ? 5 : ksize * ksize;                      // K steps per unit
   const int ct_total = (cout + 15) >> 4;
   const int nq = layout == RSA_WL_HALFPAIRS ? (cin_planes >> 1) : (cin_planes + 3) >> 2;  // units: half chunks / chunks
@@ -76,19 +90,20 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int cout, int c
       ky = s / ksize;
       kx = s - ky * ksize;
     }
-    pk_bf16x8 hi, lo;
+    pk_u16x8 hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int ci = 8 * plane + j;
       float v = 0.f;
       if (!zero && co < cout && ci < cin && plane < cin_planes) v = w[(((int64_t)co * cin + ci) * ksize + ky) * ksize + kx];
-      const __bf16 hb = (__bf16)v;
-      hi[j] = hb;
-      lo[j] = (__bf16)(v - (float)hb);
+      uint16_t h, l;
+      split_elem(v, fmt, h, l);
+      hi[j] = h;
+      lo[j] = l;
     }
     const int64_t frag = (((int64_t)q * T + s) * ct_total + ct) * nhl;  // 1 KiB fragments
-    ((pk_bf16x8*)out)[frag * 64 + lane] = hi;
-    if (nhl == 2) ((pk_bf16x8*)out)[(frag + 1) * 64 + lane] = lo;
+    ((pk_u16x8*)out)[frag * 64 + lane] = hi;
+    if (nhl == 2) ((pk_u16x8*)out)[(frag + 1) * 64 + lane] = lo;
   }
 }
 
@@ -138,33 +153,36 @@ extern "C" int64_t rsa_packed_weight_bytes_layout(int32_t cout, int32_t cin_plan
 }
 
 extern "C" int rsa_pack_weights(const float* w_oihw, int32_t cout, int32_t cin, int32_t cin_planes, int32_t ksize, int32_t products, int32_t layout,
-                                void* out, void* stream) {
+                                int32_t fmt, void* out, void* stream) {
+  if (fmt != RSA_PF_BF16 && fmt != RSA_PF_F16) return rsa::set_error(RSA_E_ARG, "pack_weights: fmt must be an rsa_plane_fmt");
   if (w_oihw == nullptr || out == nullptr || cout < 1 || cin < 1 || cin_planes < 1) return rsa::set_error(RSA_E_ARG, "pack_weights: bad argument");
   if ((ksize != 1 && ksize != 3) || (products != 1 && products != 3)) return rsa::set_error(RSA_E_ARG, "pack_weights: ksize must be 1 or 3, products 1 or 3");
   if (cin > 8 * cin_planes) return rsa::set_error(RSA_E_ARG, "pack_weights: cin does not fit in cin_planes");
   if (layout < rsa::RSA_WL_TAPS || layout > rsa::RSA_WL_UPPHASE) return rsa::set_error(RSA_E_ARG, "pack_weights: unknown layout");
   if (layout == rsa::RSA_WL_UPPHASE) {
-    if (ksize != 3 || products != 3 || cin_planes != 8 || cout != 64) return rsa::set_error(RSA_E_UNSUPPORTED, "pack_weights: the upsampling-phase layout is for 3x3, 3-product, 64 -> 64 channel layers");
+    if (ksize != 3 || products != 3 || cin_planes != 8 || cout != 64 || fmt != RSA_PF_BF16)
+      return rsa::set_error(RSA_E_UNSUPPORTED, "pack_weights: the upsampling-phase layout is for 3x3, 3-product, bf16, 64 -> 64 channel layers");
     if ((uintptr_t)out & 15) return rsa::set_error(RSA_E_ALIGN, "pack_weights: out must be 16-byte aligned");
     hipLaunchKernelGGL(rsa::pack_weights_upphase_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, out);
     const int rcu = (int)hipGetLastError();
     return rcu ? rsa::set_error(rcu, "pack_weights: launch failed") : RSA_OK;
   }
-  if (layout == rsa::RSA_WL_PAIRS && (ksize != 3 || products != 3 || (cin_planes & 3))) return rsa::set_error(RSA_E_UNSUPPORTED, "pack_weights: the tap-pair layout needs a 3x3, 3-product layer with whole 32-channel chunks");
-  if (layout == rsa::RSA_WL_HALFPAIRS && (ksize != 3 || products != 3 || (cin_planes & 1))) return rsa::set_error(RSA_E_UNSUPPORTED, "pack_weights: the half-chunk tap-pair layout needs a 3x3, 3-product layer with an even number of input planes");
+  if (layout == rsa::RSA_WL_PAIRS && (ksize != 3 || (cin_planes & 3))) return rsa::set_error(RSA_E_UNSUPPORTED, "pack_weights: the tap-pair layout needs a 3x3 layer with whole 32-channel chunks");
+  if (layout == rsa::RSA_WL_HALFPAIRS && (ksize != 3 || (cin_planes & 1))) return rsa::set_error(RSA_E_UNSUPPORTED, "pack_weights: the half-chunk tap-pair layout needs a 3x3 layer with an even number of input planes");
   if ((uintptr_t)out & 15) return rsa::set_error(RSA_E_ALIGN, "pack_weights: out must be 16-byte aligned");
+  const int nhl = products == 3 ? 2 : 1;
   const int64_t total = (layout == rsa::RSA_WL_HALFPAIRS ? (int64_t)(cin_planes / 2) * 5 : (int64_t)((cin_planes + 3) / 4) * ksize * ksize) * ((cout + 15) / 16) * 64;
   int64_t grid = (total + 255) / 256;
   if (grid > 4096) grid = 4096;
   if (layout == rsa::RSA_WL_HALFPAIRS) {  // 5 K steps per half chunk < 9 per chunk: the rest of the (fixed-size) blob is defined as zero
-    const int64_t used = total * 2 * 16, size = (int64_t)((cin_planes + 3) / 4) * 9 * ((cout + 15) / 16) * 2 * 64 * 16;
+    const int64_t used = total * nhl * 16, size = (int64_t)((cin_planes + 3) / 4) * 9 * ((cout + 15) / 16) * nhl * 64 * 16;
     if (size > used) {
       const int rc0 = (int)hipMemsetAsync((char*)out + used, 0, (size_t)(size - used), (hipStream_t)stream);
       if (rc0) return rsa::set_error(rc0, "pack_weights: memset failed");
     }
   }
   hipLaunchKernelGGL(rsa::pack_weights_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, cin_planes, ksize, products,
-                     layout, out);
+                     layout, fmt, out);
   const int rc = (int)hipGetLastError();
   return rc ? rsa::set_error(rc, "pack_weights: launch failed") : RSA_OK;
 }

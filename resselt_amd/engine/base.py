@@ -17,9 +17,34 @@ from torch import nn
 
 from . import lib as L
 from . import ops
-from .tensors import Planes, empty_f32map
+from .tensors import PF_BF16, PF_F16, Planes, empty_f32map
 
-PRECISIONS = {'bf16x3': 3, 'bf16': 1}
+# precision modes: name -> (products, plane format) of a layer the architecture has no per-layer rule for
+#   bf16x3  three bf16 products on split planes (hi + lo): ~16-bit operands, f32 range.  The conservative mode.
+#   bf16    one bf16 product (8-bit operands)
+#   fp16    one fp16 product on hi planes (11-bit operands, |v| < 65504): a third of the matrix instructions, half the activation bytes
+#   mixed   a per-layer table of the architecture (RRDBNet: residual dense blocks in one fp16 product, head / tail in three bf16 products)
+# 'auto' (the default) selects ``EngineModule.auto_precision``: the cheapest mode the architecture has pinned at <= 2e-4 max-abs
+# against the fp32 oracle in the -m gpu suite.
+PRECISIONS = {'bf16x3': (3, PF_BF16), 'bf16': (1, PF_BF16), 'fp16': (1, PF_F16), 'mixed': (3, PF_BF16)}
+
+
+class Prec(int):
+    """``products`` (1 or 3; this IS the int, so architecture code written against an int keeps working) + plane format + mode name."""
+
+    def __new__(cls, name: str):
+        products, fmt = PRECISIONS[name]
+        obj = super().__new__(cls, products)
+        obj.name, obj.fmt = name, fmt
+        return obj
+
+    @property
+    def with_lo(self) -> bool:
+        return int(self) == 3
+
+
+class Fp16Range(ValueError):
+    """A weight does not fit fp16: the module falls back to 'bf16x3' (with a warning)."""
 
 
 def conv_algorithmic_bytes(p: L.ConvParams) -> int:
@@ -29,7 +54,10 @@ def conv_algorithmic_bytes(p: L.ConvParams) -> int:
     px_in = px_out // 4 if p.upsample2x else px_out
     total = p.cin_planes * 16 * (2 if p.products == 3 else 1) * px_in
     maps = (p.cout + 3) // 4 * 16 * px_out
-    total += maps * sum(1 for r in (p.res1, p.res2, p.out_f32, p.res1_hi, p.res2_hi) if r)  # plane residuals: hi + lo = the same 4 B / channel
+    total += maps * sum(1 for r in (p.res1, p.res2, p.out_f32) if r)
+    for hi, lo in ((p.res1_hi, p.res1_lo), (p.res2_hi, p.res2_lo)):  # plane residuals: 2 B / channel per half
+        if hi:
+            total += (p.cout + 7) // 8 * 16 * (2 if lo else 1) * px_out
     if p.out_hi:
         total += (p.cout + 7) // 8 * 16 * (2 if p.out_lo else 1) * px_out
     if p.out_nchw:
@@ -47,10 +75,12 @@ class Plan:
         self.steps: list[Callable[[], None]] = []  # executed in order on the current stream
         self._pending: list[L.ConvParams] = []
         self.conv_arrays: list = []  # every flushed descriptor array, in launch order (bench.py replays single entries)
+        self.conv_cin: list = []  # per array: the layers' true input channel counts (a descriptor only knows planes of 8)
+        self._pending_cin: list = []
 
     # ---- buffers ----
-    def planes(self, n, planes, h, w, with_lo=True) -> Planes:
-        p = Planes.empty(n, planes, h, w, self.device, with_lo)
+    def planes(self, n, planes, h, w, with_lo=True, fmt: int = PF_BF16, lo_planes: int | None = None) -> Planes:
+        p = Planes.empty(n, planes, h, w, self.device, with_lo, fmt, lo_planes)
         self.keep.append(p)
         return p
 
@@ -62,6 +92,7 @@ class Plan:
     # ---- launch list ----
     def conv(self, params: L.ConvParams) -> L.ConvParams:
         self._pending.append(params)
+        self._pending_cin.append(int(getattr(params, 'true_cin', params.cin_planes * 8)))
         self._conv_bytes = getattr(self, '_conv_bytes', 0) + conv_algorithmic_bytes(params)
         return params
 
@@ -73,6 +104,8 @@ class Plan:
         self._n_launches = getattr(self, '_n_launches', 0) + len(self._pending)
         self._pending = []
         self.conv_arrays.append(arr)
+        self.conv_cin.append(self._pending_cin)
+        self._pending_cin = []
         dev = self.device
         self.steps.append(lambda: L.conv2d_list(arr, ops.current_stream_ptr(dev)))
         return arr
@@ -104,7 +137,9 @@ class Plan:
         self.keep.clear()
         self.steps.clear()
         self.conv_arrays.clear()
+        self.conv_cin.clear()
         self._pending = []
+        self._pending_cin = []
 
     def buffer_bytes(self) -> int:
         total = 0
@@ -112,7 +147,7 @@ class Plan:
             if k is None:
                 continue
             if isinstance(k, Planes):
-                total += k.hi.numel() * 2 * (2 if k.lo is not None else 1)
+                total += k.nbytes()
             elif isinstance(k, torch.Tensor):
                 total += k.numel() * k.element_size()
         return total
@@ -123,7 +158,7 @@ class EngineModule(nn.Module):
 
     def __init__(self):
         super().__init__()
-        self.precision: str = 'bf16x3'
+        self.precision: str = 'auto'  # 'auto' | 'bf16x3' | 'bf16' | whatever else ``precisions`` lists (see PRECISIONS)
         # Replay the whole forward as ONE hipGraph (torch.cuda.CUDAGraph) per input signature: removes the per-launch host cost and most of
         # the inter-kernel gaps, which dominate for small images (351 launches of ~10 us each for RRDBNet-23 at 256x256).  Costs one copy
         # of the input into, and of the output out of, graph-owned buffers.  Off by default.
@@ -159,6 +194,7 @@ class EngineModule(nn.Module):
 
     def _invalidate(self) -> None:
         self._packed = {}
+        self._fp16_refused = False
         for key in list(getattr(self, '_plans', {})):
             self._drop_plan(key)
         self._plans = {}
@@ -193,12 +229,22 @@ class EngineModule(nn.Module):
             return None
         return list(self._plans.values())[-1][0].conv_bytes()
 
+    #: what ``precision = 'auto'`` resolves to, and the modes this architecture implements (subclasses widen both)
+    auto_precision = 'bf16x3'
+    precisions = ('bf16x3', 'bf16')
+
+    def resolved_precision(self) -> str:
+        name = self.precision
+        if name == 'auto':
+            name = 'bf16x3' if getattr(self, '_fp16_refused', False) else self.auto_precision
+        if name not in self.precisions:
+            raise ValueError(f"precision must be 'auto' or one of {list(self.precisions)} for {type(self).__name__}, got {self.precision!r}")
+        return name
+
     @property
-    def products(self) -> int:
-        try:
-            return PRECISIONS[self.precision]
-        except KeyError:
-            raise ValueError(f'precision must be one of {sorted(PRECISIONS)}, got {self.precision!r}') from None
+    def products(self) -> Prec:
+        """The resolved precision as an int-compatible ``Prec`` (``int(prec)`` = matrix products per layer without a per-layer rule)."""
+        return Prec(self.resolved_precision())
 
     # -- hooks --
     def _pack(self, device, products: int):
@@ -209,7 +255,7 @@ class EngineModule(nn.Module):
         raise NotImplementedError
 
     def _weights(self, device):
-        key = (str(device), self.products)
+        key = (str(device), self.resolved_precision())
         # in-place edits of a parameter (p.data.copy_, optimizer steps, load into .data) bump its version counter: repack when any changed
         versions = tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
         if versions != self._packed_versions:
@@ -218,7 +264,18 @@ class EngineModule(nn.Module):
         w = self._packed.get(key)
         if w is None:
             with torch.no_grad():
-                w = self._pack(device, self.products)
+                try:
+                    w = self._pack(device, self.products)
+                except Fp16Range as e:
+                    if self.precision != 'auto':
+                        raise
+                    # pack-time guard of the fp16 modes: a weight beyond the fp16 range -> the conservative mode, and say so
+                    import warnings
+
+                    warnings.warn(f'{type(self).__name__}: {e}; precision "auto" falls back to "bf16x3"', RuntimeWarning, stacklevel=3)
+                    self._fp16_refused = True
+                    key = (str(device), self.resolved_precision())
+                    w = self._pack(device, self.products)
             self._packed = {key: w}
             for k in list(self._plans):
                 self._drop_plan(k)
@@ -262,7 +319,7 @@ class EngineModule(nn.Module):
         if first is not None and first.device != x.device:
             raise RuntimeError(f'model parameters are on {first.device} but the input is on {x.device}')
         packed = self._weights(x.device)
-        key = (shape, x.dtype, str(x.device), self.products)
+        key = (shape, x.dtype, str(x.device), self.resolved_precision())
         entry = self._plans.pop(key, None)
         if entry is None:
             plan = Plan(x.device)
@@ -278,6 +335,9 @@ class EngineModule(nn.Module):
             if not self.use_graph:
                 set_input(x.contiguous())
                 plan.run()
+                # a host-visible word, no synchronisation: raises for a failed ring hand-off of any launch that has completed by now
+                # (at the latest, the next forward or an explicit L.check_status() after a synchronise reports this one's)
+                L.check_status(type(self).__name__)
                 return get_output()
             if graph is None:
                 static_x = x.contiguous().clone()

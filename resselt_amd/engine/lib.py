@@ -18,6 +18,9 @@ _lib: Optional[C.CDLL] = None
 ACT_NONE, ACT_LRELU, ACT_MISH, ACT_SILU, ACT_GELU, ACT_SPAB_GATE, ACT_PRELU = range(7)
 # enum rsa_dtype
 F32, F16, BF16, U8 = range(4)
+# enum rsa_plane_fmt
+PF_BF16, PF_F16 = range(2)
+E_INTERNAL = -4
 
 
 class ConvParams(C.Structure):
@@ -67,6 +70,10 @@ class ConvParams(C.Structure):
         ('res2_lo', C.c_void_p),
         ('res_plane_stride', C.c_int64),
         ('res_batch_stride', C.c_int64),
+        ('in_fmt', C.c_int32),
+        ('out_fmt', C.c_int32),
+        ('res_fmt', C.c_int32),
+        ('reserved0', C.c_int32),
     ]
 
 
@@ -397,7 +404,9 @@ EXPORTS = (
     'rsa_conv_weight_layout',
     'rsa_pack_weights',
     'rsa_conv_kernel_name',
+    'rsa_check_status',
     'rsa_debug_ring_aborts',
+    'rsa_debug_set_ring_spin_limit',
     'rsa_debug_set_ring',
     'rsa_nchw_to_planes',
     'rsa_planes_to_nchw',
@@ -479,7 +488,7 @@ def load() -> C.CDLL:
     lib.rsa_packed_weight_bytes_layout.restype = C.c_int64
     lib.rsa_conv_weight_layout.argtypes = [C.POINTER(ConvParams)]
     lib.rsa_conv_weight_layout.restype = C.c_int
-    lib.rsa_pack_weights.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.rsa_pack_weights.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.rsa_pack_weights.restype = C.c_int
     lib.rsa_conv_kernel_name.argtypes = [C.POINTER(ConvParams)]
     lib.rsa_conv_kernel_name.restype = C.c_char_p
@@ -487,13 +496,17 @@ def load() -> C.CDLL:
     lib.rsa_debug_ring_aborts.restype = C.c_int
     lib.rsa_debug_set_ring.argtypes = [C.c_int32]
     lib.rsa_debug_set_ring.restype = C.c_int
+    lib.rsa_debug_set_ring_spin_limit.argtypes = [C.c_int32]
+    lib.rsa_debug_set_ring_spin_limit.restype = C.c_int
+    lib.rsa_check_status.argtypes = []
+    lib.rsa_check_status.restype = C.c_int
     lib.rsa_nchw_to_planes.argtypes = [
         C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_float,
-        C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+        C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
     ]  # fmt: skip
     lib.rsa_nchw_to_planes.restype = C.c_int
     lib.rsa_planes_to_nchw.argtypes = [
-        C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+        C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
     ]  # fmt: skip
     lib.rsa_planes_to_nchw.restype = C.c_int
     lib.rsa_dysample.argtypes = [C.POINTER(DySampleParams), C.c_void_p]
@@ -562,6 +575,16 @@ def conv_kernel_name(p: ConvParams) -> str:
 
 def ring_aborts() -> int:
     return int(load().rsa_debug_ring_aborts())
+
+
+def check_status(what: str = 'forward') -> None:
+    """Raise when a ring-schedule kernel of a COMPLETED launch reported a failed hand-off (``rsa_check_status``: reads a host-visible word,
+    never synchronises).  Synchronise the stream first to judge the launches still in flight."""
+    check(load().rsa_check_status(), f'{what}: rsa_check_status')
+
+
+def set_ring_spin_limit(polls: int) -> None:
+    load().rsa_debug_set_ring_spin_limit(int(polls))
 
 
 def cout_tiles(cout: int) -> int:

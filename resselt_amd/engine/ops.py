@@ -9,7 +9,7 @@ import torch
 
 from . import lib as L
 from .pack import pack_conv_weights, pad_bias  # noqa: F401  (pad_bias re-exported for the model files)
-from .tensors import Planes
+from .tensors import PF_BF16, PF_F16, Planes  # noqa: F401
 
 _TORCH_TO_RSA = {torch.float32: L.F32, torch.float16: L.F16, torch.bfloat16: L.BF16, torch.uint8: L.U8}
 
@@ -34,8 +34,9 @@ def require_cuda(x: torch.Tensor, what: str) -> None:
         )
 
 
-def pack_weights_device(w: torch.Tensor, cin_planes: int, products: int, layout: int) -> torch.Tensor:
-    """OIHW f32 weights on the GPU -> packed A-fragment blob (``rsa_pack_weights``, one kernel; csrc/pack.hip)."""
+def pack_weights_device(w: torch.Tensor, cin_planes: int, products: int, layout: int, fmt: int = PF_BF16) -> torch.Tensor:
+    """OIHW f32 weights on the GPU -> packed A-fragment blob (``rsa_pack_weights``, one kernel; csrc/pack.hip).  The blob is returned as
+    a bf16-typed tensor whatever ``fmt`` says: it is an opaque 16-bit container."""
     require_cuda(w, 'pack_weights')
     w = w.to(torch.float32).contiguous()
     cout, cin, k, _ = w.shape
@@ -45,8 +46,8 @@ def pack_weights_device(w: torch.Tensor, cin_planes: int, products: int, layout:
         raise ValueError(f'unsupported convolution shape cout={cout} cin_planes={cin_planes} k={k} products={products}')
     out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
     with torch.cuda.device(w.device):
-        L.check(lib.rsa_pack_weights(w.data_ptr(), cout, cin, cin_planes, k, products, layout, out.data_ptr(), C.c_void_p(current_stream_ptr(w.device))),
-                'rsa_pack_weights')  # fmt: skip
+        L.check(lib.rsa_pack_weights(w.data_ptr(), cout, cin, cin_planes, k, products, layout, fmt, out.data_ptr(),
+                                     C.c_void_p(current_stream_ptr(w.device))), 'rsa_pack_weights')  # fmt: skip
     return out
 
 
@@ -64,9 +65,10 @@ class ConvWeights:
     products: int
     w: torch.Tensor | None = None  # f32 OIHW source on the device
     _by_layout: dict | None = None
+    fmt: int = PF_BF16  # enum rsa_plane_fmt of the blob = of the input planes this layer multiplies
 
     @staticmethod
-    def from_oihw(w: torch.Tensor, b: torch.Tensor | None, products: int, cin_planes: int | None = None, device=None) -> 'ConvWeights':
+    def from_oihw(w: torch.Tensor, b: torch.Tensor | None, products: int, cin_planes: int | None = None, device=None, fmt: int = PF_BF16) -> 'ConvWeights':
         device = device if device is not None else w.device
         cout, cin, k, _ = w.shape
         if cin_planes is None:
@@ -74,7 +76,8 @@ class ConvWeights:
         if cin > 8 * cin_planes:
             raise ValueError(f'cin={cin} does not fit in {cin_planes} planes')
         bias = pad_bias(None if b is None else b.to(device), cout, device)
-        return ConvWeights(None, bias, cout, cin, cin_planes, k, products, w=w.detach().to(device=device, dtype=torch.float32).contiguous(), _by_layout={})
+        return ConvWeights(None, bias, cout, cin, cin_planes, k, products, w=w.detach().to(device=device, dtype=torch.float32).contiguous(), _by_layout={},
+                           fmt=fmt)  # fmt: skip
 
     def packed_for(self, layout: int) -> torch.Tensor:
         if self.w is None:  # a blob written directly by a kernel (e.g. rsa_channel_attention_weights): layout 0 only
@@ -83,7 +86,7 @@ class ConvWeights:
             return self.packed
         blob = self._by_layout.get(layout)
         if blob is None:
-            blob = self._by_layout[layout] = pack_weights_device(self.w, self.cin_planes, self.products, layout)
+            blob = self._by_layout[layout] = pack_weights_device(self.w, self.cin_planes, self.products, layout, self.fmt)
             if layout == 0:
                 self.packed = blob
         return blob
@@ -132,9 +135,15 @@ def conv_params(
     if in_plane0 + p.cin_planes > x.planes:
         raise ValueError('input plane range exceeds the buffer')
     p.in_hi = x.hi_ptr(in_plane0)
-    p.in_lo = x.lo_ptr(in_plane0)
-    if wts.products == 3 and x.lo is None:
-        raise ValueError('products=3 needs lo planes')
+    if x.fmt != wts.fmt:
+        raise ValueError(f'input planes are in plane format {x.fmt} but the weights were packed for {wts.fmt}')
+    p.in_fmt = wts.fmt
+    if wts.products == 3:
+        if not x.has_lo(in_plane0, p.cin_planes):
+            raise ValueError('products=3 needs lo planes for every input plane')
+        p.in_lo = x.lo_ptr(in_plane0)
+    else:
+        p.in_lo = None
     p.in_plane_stride = x.plane_stride
     p.in_batch_stride = x.batch_stride
     p.bias = wts.bias.data_ptr()
@@ -159,17 +168,22 @@ def conv_params(
                 raise ValueError(f'{name} must be a contiguous f32 [N,{p4},{H},{W},4] map, got {tuple(r.shape)} {r.dtype}')
     p.res1 = None if res1 is None or 'res1' in plane_res else res1.data_ptr()
     p.res2 = None if res2 is None or 'res2' in plane_res else res2.data_ptr()
+    if len({pl.fmt for pl, _ in plane_res.values()}) > 1:
+        raise ValueError('res1 and res2 plane residuals must share their plane format')
     for name, (pl, plane0) in plane_res.items():
         setattr(p, f'{name}_hi', pl.hi_ptr(plane0))
-        setattr(p, f'{name}_lo', pl.lo_ptr(plane0))
+        setattr(p, f'{name}_lo', pl.lo_ptr(plane0) if pl.has_lo(plane0, (wts.cout + 7) // 8) else None)
         p.res_plane_stride, p.res_batch_stride = pl.plane_stride, pl.batch_stride
+        p.res_fmt = pl.fmt
     p.out_f32 = None if out_f32 is None else out_f32.data_ptr()
     nplanes_out = (wts.cout + 7) // 8
     if out is not None:
         if (out.h, out.w, out.n) != (H, W, x.n) or out_plane_off + nplanes_out > out.planes:
             raise ValueError('output planes do not match the convolution output')
         p.out_hi = out.hi_ptr()
-        p.out_lo = out.lo_ptr()
+        # lo halves are written only where the buffer keeps them for EVERY plane this layer writes (see tensors.Planes.empty: lo_planes)
+        p.out_lo = out.lo_ptr() if out.has_lo(out_plane_off, nplanes_out) else None
+        p.out_fmt = out.fmt
         p.out_plane_off = out_plane_off
         p.out_plane_stride = out.plane_stride
         p.out_batch_stride = out.batch_stride
@@ -199,6 +213,7 @@ def conv_params(
     # the schedule this descriptor dispatches to decides the K order of the weight blob
     p.w_layout = int(L.load().rsa_conv_weight_layout(C.byref(p)))
     p.w_packed = wts.packed_for(p.w_layout).data_ptr()
+    p.true_cin = min(wts.cin, 8 * p.cin_planes)  # python-side only (not part of the C struct): FLOP accounting in bench.py
     return p
 
 
@@ -206,7 +221,7 @@ def run_convs(params: list[L.ConvParams], device) -> None:
     L.conv2d_list(params, current_stream_ptr(device))
 
 
-def nchw_to_planes(x: torch.Tensor, out: Planes, mean: torch.Tensor | None = None, scale: float = 1.0, unshuffle: int = 1) -> None:
+def nchw_to_planes(x: torch.Tensor, out: Planes, mean: torch.Tensor | None = None, scale: float = 1.0, unshuffle: int = 1) -> None:  # noqa: C901
     """Plain [N,C,h,w] tensor -> split planes on the GPU (rsa_nchw_to_planes).
 
     ``out`` may be larger than ``x`` (up to 2x-1): the extra rows/columns are reflect-padded (SwinIR window padding).
@@ -226,7 +241,8 @@ def nchw_to_planes(x: torch.Tensor, out: Planes, mean: torch.Tensor | None = Non
     L.check(
         lib.rsa_nchw_to_planes(
             x.data_ptr(), rsa_dtype(x.dtype), n, c, out.h, out.w, h, w, r, None if mean is None else mean.data_ptr(), scale,
-            out.hi_ptr(), out.lo_ptr(), out.plane_stride, out.batch_stride, C.c_void_p(current_stream_ptr(x.device)),
+            out.hi_ptr(), out.lo_ptr() if out.has_lo(0, (c * r * r + 7) // 8) else None, out.plane_stride, out.batch_stride, out.fmt,
+            C.c_void_p(current_stream_ptr(x.device)),
         ),
         'rsa_nchw_to_planes',
     )  # fmt: skip
@@ -238,8 +254,8 @@ def planes_to_nchw(p: Planes, channels: int) -> torch.Tensor:
     lib = L.load()
     L.check(
         lib.rsa_planes_to_nchw(
-            p.hi_ptr(), p.lo_ptr(), p.plane_stride, p.batch_stride, p.n, channels, p.h, p.w, out.data_ptr(),
-            C.c_void_p(current_stream_ptr(out.device)),
+            p.hi_ptr(), p.lo_ptr() if p.has_lo(0, (channels + 7) // 8) else None, p.plane_stride, p.batch_stride, p.n, channels, p.h, p.w, p.fmt,
+            out.data_ptr(), C.c_void_p(current_stream_ptr(out.device)),
         ),
         'rsa_planes_to_nchw',
     )  # fmt: skip

@@ -27,12 +27,16 @@ from __future__ import annotations
 import torch
 
 
-def split_bf16(x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
-    """x (f32) -> (hi, lo) bf16 with hi = RNE(x), lo = RNE(x - hi)."""
+def split_halves(x: torch.Tensor, dtype: torch.dtype = torch.bfloat16) -> tuple[torch.Tensor, torch.Tensor]:
+    """x (f32) -> (hi, lo) in ``dtype`` (bf16 or fp16) with hi = RNE(x), lo = RNE(x - hi)."""
     x = x.to(torch.float32)
-    hi = x.to(torch.bfloat16)
-    lo = (x - hi.to(torch.float32)).to(torch.bfloat16)
+    hi = x.to(dtype)
+    lo = (x - hi.to(torch.float32)).to(dtype)
     return hi, lo
+
+
+def split_bf16(x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    return split_halves(x, torch.bfloat16)
 
 
 def packed_weight_shape(cout: int, cin_planes: int, ksize: int, products: int) -> tuple[int, ...]:
@@ -41,8 +45,8 @@ def packed_weight_shape(cout: int, cin_planes: int, ksize: int, products: int) -
     return (q, ksize * ksize, ct, 2 if products == 3 else 1, 64, 8)
 
 
-def pack_conv_weights(w: torch.Tensor, cin_planes: int, products: int = 3) -> torch.Tensor:
-    """OIHW f32 weights -> MFMA A-fragment blob (bf16, contiguous)."""
+def pack_conv_weights(w: torch.Tensor, cin_planes: int, products: int = 3, dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """OIHW f32 weights -> MFMA A-fragment blob (``dtype`` = bf16 or fp16, contiguous)."""
     if w.dim() != 4 or w.shape[2] != w.shape[3] or w.shape[2] not in (1, 3):
         raise ValueError(f'expected [cout, cin, k, k] with k in (1, 3), got {tuple(w.shape)}')
     cout, cin, k, _ = w.shape
@@ -54,7 +58,7 @@ def pack_conv_weights(w: torch.Tensor, cin_planes: int, products: int = 3) -> to
     q = (cin_planes + 3) // 4
     wp = torch.zeros((ct * 16, q * 32, k * k), dtype=torch.float32, device=w.device)
     wp[:cout, :cin] = w.to(torch.float32).reshape(cout, cin, k * k)
-    hi, lo = split_bf16(wp)
+    hi, lo = split_halves(wp, dtype)
 
     def frag(x: torch.Tensor) -> torch.Tensor:
         # [ct, i, q, g, j, t] -> [q, t, ct, g, i, j] -> lanes g*16+i
@@ -74,8 +78,8 @@ def pair_layout_index(s: int, lg: int) -> tuple[int, int, int]:
     return 2 * half + (lg & 1), ky, kx
 
 
-def pack_conv_weights_pairs(w: torch.Tensor, cin_planes: int) -> torch.Tensor:
-    """OIHW f32 3x3 weights -> blob in the tap-pair layout (three products)."""
+def pack_conv_weights_pairs(w: torch.Tensor, cin_planes: int, products: int = 3, dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """OIHW f32 3x3 weights -> blob in the tap-pair layout (hi and lo for three products, hi only for one)."""
     cout, cin, k, _ = w.shape
     if k != 3 or cin_planes % 4 or cin > 8 * cin_planes:
         raise ValueError('the tap-pair layout needs a 3x3 layer with whole 32-channel chunks')
@@ -83,19 +87,20 @@ def pack_conv_weights_pairs(w: torch.Tensor, cin_planes: int) -> torch.Tensor:
     q = cin_planes // 4
     wp = torch.zeros((ct * 16, q * 32, 3, 3), dtype=torch.float32, device=w.device)
     wp[:cout, :cin] = w.to(torch.float32)
-    hi, lo = split_bf16(wp)
-    out = torch.zeros((q, 9, ct, 2, 64, 8), dtype=torch.bfloat16, device=w.device)
+    hi, lo = split_halves(wp, dtype)
+    nhl = 2 if products == 3 else 1
+    out = torch.zeros((q, 9, ct, nhl, 64, 8), dtype=dtype, device=w.device)
     for s in range(9):
         for lg in range(4):
             pl, ky, kx = pair_layout_index(s, lg)
-            for hl, src in enumerate((hi, lo)):
+            for hl, src in enumerate((hi, lo)[:nhl]):
                 # [ct*16, q*32] -> [q, ct, 16 lanes, 8]
                 v = src[:, :, ky, kx].reshape(ct, 16, q, 4, 8)[:, :, :, pl, :].permute(2, 0, 1, 3)
                 out[:, s, :, hl, lg * 16 : lg * 16 + 16, :] = v
     return out.contiguous()
 
 
-def pack_conv_weights_halfpairs(w: torch.Tensor, cin_planes: int) -> torch.Tensor:
+def pack_conv_weights_halfpairs(w: torch.Tensor, cin_planes: int, products: int = 3, dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
     """Layout 2 (half mode of the ring schedule: an odd number of 16-channel half chunks): packed[half][s 0..4][ct][hl][lane][j];
     lane group lg reads plane 2*half + (lg & 1); s = 0,1,2: tap (ky = s, kx = h); s = 3: tap (ky = h, kx = 2); s = 4: tap (2,2) for
     h = lg >> 1 == 0 and ZERO weights for h == 1.  The blob is allocated at the size of the chunked layouts; the tail stays zero."""
@@ -106,18 +111,19 @@ def pack_conv_weights_halfpairs(w: torch.Tensor, cin_planes: int) -> torch.Tenso
     nh = cin_planes // 2
     wp = torch.zeros((ct * 16, nh * 16, 3, 3), dtype=torch.float32, device=w.device)
     wp[:cout, :cin] = w.to(torch.float32)
-    hi, lo = split_bf16(wp)
-    out = torch.zeros((nh, 5, ct, 2, 64, 8), dtype=torch.bfloat16, device=w.device)
+    hi, lo = split_halves(wp, dtype)
+    nhl = 2 if products == 3 else 1
+    out = torch.zeros((nh, 5, ct, nhl, 64, 8), dtype=dtype, device=w.device)
     for s in range(5):
         for lg in range(4):
             h = lg >> 1
             if s == 4 and h:
                 continue
             ky, kx = (s, h) if s < 3 else ((h, 2) if s == 3 else (2, 2))
-            for hl, src in enumerate((hi, lo)):
+            for hl, src in enumerate((hi, lo)[:nhl]):
                 v = src[:, :, ky, kx].reshape(ct, 16, nh, 2, 8)[:, :, :, lg & 1, :].permute(2, 0, 1, 3)  # [nh, ct, 16 lanes, 8]
                 out[:, s, :, hl, lg * 16 : lg * 16 + 16, :] = v
-    full = torch.zeros(packed_weight_shape(cout, cin_planes, 3, 3), dtype=torch.bfloat16, device=w.device).reshape(-1)
+    full = torch.zeros(packed_weight_shape(cout, cin_planes, 3, products), dtype=dtype, device=w.device).reshape(-1)
     full[: out.numel()] = out.reshape(-1)
     return full
 

@@ -1,7 +1,11 @@
 """Device buffers in the engine's HBM layouts (include/resselt_amd.h, "Activation storage").
 
-``Planes``   split-bf16 feature map  hi/lo[N][P][H][W][8]   (P planes of 8 channels, 16-byte units)
+``Planes``   split feature map       hi/lo[N][P][H][W][8]   (P planes of 8 channels, 16-byte units; bf16 or fp16: ``fmt``)
 ``f32 map``  residual stream         f32[N][P4][H][W][4]
+
+A ``Planes`` buffer may carry ``lo`` for its first ``lo_planes`` planes only (the residual stream of a residual dense block under the
+one-product fp16 policy: the 64 trunk channels keep 22 bits, the growth channels 11): hi and lo then live in ONE allocation
+``[N][P + lo_planes][H][W][8]`` so that both share the batch stride the kernels apply to either pointer.
 
 Both are ordinary torch tensors so the PyTorch caching allocator owns the memory; the kernels
 only ever see raw pointers and strides (in 16-byte units).
@@ -13,17 +17,36 @@ from dataclasses import dataclass
 
 import torch
 
+PF_BF16, PF_F16 = 0, 1  # enum rsa_plane_fmt
+_PF_DTYPE = {PF_BF16: torch.bfloat16, PF_F16: torch.float16}
+
 
 @dataclass
 class Planes:
-    hi: torch.Tensor  # [N, P, H, W, 8] bf16
-    lo: torch.Tensor | None  # same shape, or None in single-product (plain bf16) mode
+    hi: torch.Tensor  # [N, P, H, W, 8] bf16 or fp16 (dense, or the first P planes of a [N, P + lo_planes, ...] allocation)
+    lo: torch.Tensor | None  # [N, lo_planes <= P, H, W, 8] of the same dtype, or None (one-product consumers only)
 
     @staticmethod
-    def empty(n: int, planes: int, h: int, w: int, device, with_lo: bool = True) -> 'Planes':
-        hi = torch.empty((n, planes, h, w, 8), dtype=torch.bfloat16, device=device)
-        lo = torch.empty_like(hi) if with_lo else None
-        return Planes(hi, lo)
+    def empty(n: int, planes: int, h: int, w: int, device, with_lo: bool = True, fmt: int = PF_BF16, lo_planes: int | None = None) -> 'Planes':
+        dt = _PF_DTYPE[fmt]
+        if not with_lo or lo_planes == 0:
+            return Planes(torch.empty((n, planes, h, w, 8), dtype=dt, device=device), None)
+        if lo_planes is None or lo_planes >= planes:
+            hi = torch.empty((n, planes, h, w, 8), dtype=dt, device=device)
+            return Planes(hi, torch.empty_like(hi))
+        store = torch.empty((n, planes + lo_planes, h, w, 8), dtype=dt, device=device)
+        return Planes(store[:, :planes], store[:, planes:])
+
+    @property
+    def fmt(self) -> int:
+        return PF_F16 if self.hi.dtype == torch.float16 else PF_BF16
+
+    @property
+    def lo_planes(self) -> int:
+        return 0 if self.lo is None else self.lo.shape[1]
+
+    def nbytes(self) -> int:
+        return (self.hi.shape[1] + self.lo_planes) * self.hi.shape[0] * self.h * self.w * 16
 
     @property
     def n(self) -> int:
@@ -46,8 +69,8 @@ class Planes:
         return self.h * self.w
 
     @property
-    def batch_stride(self) -> int:
-        return self.planes * self.h * self.w
+    def batch_stride(self) -> int:  # units of 16 bytes (hi and lo share it: see ``empty``)
+        return self.hi.stride(0) // 8
 
     def hi_ptr(self, plane: int = 0) -> int:
         return self.hi.data_ptr() + plane * self.plane_stride * 16
@@ -56,6 +79,10 @@ class Planes:
         if self.lo is None:
             return None
         return self.lo.data_ptr() + plane * self.plane_stride * 16
+
+    def has_lo(self, plane0: int, nplanes: int) -> bool:
+        """Whether planes [plane0, plane0 + nplanes) all carry lo halves."""
+        return self.lo is not None and plane0 + nplanes <= self.lo.shape[1]
 
 
 class PlaneRows:
@@ -69,6 +96,8 @@ class PlaneRows:
         self.hi, self.lo = base.hi, base.lo  # (the whole tensors: kept alive by whoever holds the view)
 
     n = property(lambda self: self.base.n)
+    fmt = property(lambda self: self.base.fmt)
+    lo_planes = property(lambda self: self.base.lo_planes)
     planes = property(lambda self: self.base.planes)
     w = property(lambda self: self.base.w)
     h = property(lambda self: self.r1 - self.r0)
@@ -82,6 +111,9 @@ class PlaneRows:
         p = self.base.lo_ptr(plane)
         return None if p is None else p + self.r0 * self.base.w * 16
 
+    def has_lo(self, plane0: int, nplanes: int) -> bool:
+        return self.base.has_lo(plane0, nplanes)
+
 
 def empty_f32map(n: int, channels: int, h: int, w: int, device) -> torch.Tensor:
     return torch.empty((n, (channels + 3) // 4, h, w, 4), dtype=torch.float32, device=device)
@@ -93,20 +125,21 @@ def empty_f32map(n: int, channels: int, h: int, w: int, device) -> torch.Tensor:
 def planes_to_nchw(p: Planes, channels: int) -> torch.Tensor:
     v = p.hi.to(torch.float32)
     if p.lo is not None:
-        v = v + p.lo.to(torch.float32)
+        v = v.clone()
+        v[:, : p.lo.shape[1]] += p.lo.to(torch.float32)
     n, pl, h, w, _ = v.shape
     return v.permute(0, 1, 4, 2, 3).reshape(n, pl * 8, h, w)[:, :channels].contiguous()
 
 
-def nchw_to_planes(x: torch.Tensor, with_lo: bool = True) -> Planes:
-    from .pack import split_bf16
+def nchw_to_planes(x: torch.Tensor, with_lo: bool = True, fmt: int = PF_BF16) -> Planes:
+    from .pack import split_halves
 
     n, c, h, w = x.shape
     pl = (c + 7) // 8
     xp = torch.zeros((n, pl * 8, h, w), dtype=torch.float32, device=x.device)
     xp[:, :c] = x.to(torch.float32)
     xp = xp.reshape(n, pl, 8, h, w).permute(0, 1, 3, 4, 2).contiguous()
-    hi, lo = split_bf16(xp)
+    hi, lo = split_halves(xp, _PF_DTYPE[fmt])
     return Planes(hi.contiguous(), lo.contiguous() if with_lo else None)
 
 

@@ -1,0 +1,216 @@
+"""GPU parity of the fp16 plane format (round 3): one fp16 product on hi planes (`products = 1, fmt = RSA_PF_F16`: the ring schedule with
+eight LDS slots, and the chunk-barrier kernels for the shapes the ring does not take), three fp16 products for the four-tile shape, fp16
+plane outputs / residuals of the epilogue, and `rsa_pack_weights(fmt)`.
+
+The reference of a one-product layer is the f32 convolution of the fp16-ROUNDED operands: every product of two 11-bit values is exact in
+f32, so the kernel may differ from it by accumulation order only (tolerance 1e-5 * scale); against the unrounded fp32 convolution the
+error is the operand rounding itself (2^-11 per operand), checked at 2e-3 * scale.
+"""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from resselt_amd.engine import lib as L
+from resselt_amd.engine import ops, pack, tensors
+from resselt_amd.engine.tensors import PF_BF16, PF_F16
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def _h(t):
+    return t.half().float()
+
+
+def _conv(x, w, b=None):
+    return F.conv2d(x.double(), w.double(), None if b is None else b.double(), padding=w.shape[-1] // 2).float()
+
+
+@pytest.mark.parametrize(
+    'n,cin,cout,h,w,k',
+    [
+        (2, 64, 32, 20, 45, 3),  # ring SHAPE 2 (two streams, eight slots), ragged tile edges
+        (1, 160, 32, 33, 70, 3),  # five chunks: the weight ring wraps inside a tile
+        (1, 192, 64, 19, 37, 3),  # ring SHAPE 1 (conv5)
+        (1, 64, 64, 40, 40, 3),
+        (1, 48, 48, 24, 24, 3),  # ring SHAPE 3, half mode
+        (1, 96, 48, 17, 50, 3),  # ring SHAPE 3, whole chunks
+        (1, 3, 48, 16, 32, 3),  # chunk-barrier kernel, channel padding 3 -> 8
+        (1, 64, 3, 17, 31, 3),  # chunk-barrier kernel, one cout tile
+        (1, 192, 48, 8, 40, 1),  # k1 (SPAN conv_cat)
+        (1, 240, 720, 8, 32, 1),  # k1, several cout slabs
+    ],
+)
+def test_conv_one_fp16_product(device, n, cin, cout, h, w, k):
+    x = _rand((n, cin, h, w), 1)
+    wt = _rand((cout, cin, k, k), 2, 1.0 / (cin * k * k) ** 0.5)
+    b = _rand((cout,), 3, 0.1)
+    ref = _conv(_h(x), _h(wt), b)
+    exact = _conv(x, wt, b)
+    wts = ops.ConvWeights.from_oihw(wt, b, 1, device=device, fmt=PF_F16)
+    xin = tensors.nchw_to_planes(x.to(device), with_lo=False, fmt=PF_F16)
+    out = tensors.Planes.empty(n, (cout + 7) // 8, h, w, device, with_lo=False, fmt=PF_F16)
+    out2 = tensors.Planes.empty(n, (cout + 7) // 8, h, w, device, with_lo=True, fmt=PF_F16)
+    of32 = tensors.empty_f32map(n, cout, h, w, device)
+    onchw = torch.empty((n, cout, h, w), dtype=torch.float32, device=device)
+    ps = [ops.conv_params(wts, xin, h, w, out=out), ops.conv_params(wts, xin, h, w, out=out2, out_f32=of32), ops.conv_params(wts, xin, h, w, out_nchw=onchw)]
+    assert all(p.in_fmt == PF_F16 and p.products == 1 for p in ps)
+    ops.run_convs(ps, device)
+    torch.cuda.synchronize()
+    assert L.ring_aborts() == 0
+    L.check_status('test')
+    scale = ref.abs().max().item()
+    for name, got in (('out_nchw', onchw.cpu()), ('out_f32', tensors.f32map_to_nchw(of32, cout).cpu())):
+        assert (got - ref).abs().max().item() <= 1e-5 * scale, name
+        assert (got - exact).abs().max().item() <= 2e-3 * scale, name
+    # hi-only fp16 planes: the value rounded to fp16; hi + lo planes: 22 bits
+    hi_only = tensors.planes_to_nchw(out, cout).cpu()
+    assert (hi_only - ref).abs().max().item() <= 2.0**-11 * scale * 1.01 + 1e-5 * scale
+    both = tensors.planes_to_nchw(out2, cout).cpu()
+    assert (both - ref).abs().max().item() <= 1.2e-5 * scale
+    full = tensors.planes_to_nchw(out, out.planes * 8)
+    if out.planes * 8 > cout:
+        assert full[:, cout:].abs().max().item() == 0.0
+
+
+def test_rdb_under_the_mixed_policy(device):
+    """One residual dense block as the 'mixed' plan runs it: growth convolutions in one fp16 product writing hi-only planes at plane
+    offsets of a workspace whose first 8 planes keep hi + lo, conv5 with `x5 * 0.2 + x` and the RRDB residual from fp16 planes."""
+    n, h, w, pf, pg = 1, 37, 70, 8, 4
+    g = torch.Generator().manual_seed(5)
+    x = _rand((n, 64, h, w), 5)
+    x0 = _rand((n, 64, h, w), 6)
+    ws = tensors.Planes.empty(n, pf + 4 * pg, h, w, device, True, PF_F16, lo_planes=pf)
+    ws.hi.zero_()
+    src = tensors.nchw_to_planes(x.to(device), True, PF_F16)
+    ws.hi[:, :pf] = src.hi
+    ws.lo[:, :pf] = src.lo
+    r0src = tensors.nchw_to_planes(x0.to(device), True, PF_F16)
+    r0 = tensors.Planes.empty(n, pf + 4 * pg, h, w, device, True, PF_F16, lo_planes=pf)  # another workspace: both residuals share their strides
+    r0.hi[:, :pf] = r0src.hi
+    r0.lo[:, :pf] = r0src.lo
+    out = tensors.Planes.empty(n, pf, h, w, device, True, PF_F16)
+    ps, keep = [], []  # (a descriptor holds raw pointers: the weight blobs must outlive the launch)
+    cat = _h(tensors.planes_to_nchw(src, 64).cpu())
+    for j in range(1, 6):
+        cin, cout = 64 + 32 * (j - 1), 32 if j < 5 else 64
+        wt = (torch.rand((cout, cin, 3, 3), generator=g) * 2 - 1) / (cin * 9) ** 0.5
+        b = (torch.rand((cout,), generator=g) * 2 - 1) * 0.1
+        wts = ops.ConvWeights.from_oihw(wt, b, 1, device=device, fmt=PF_F16)
+        keep.append(wts)
+        y = _conv(cat, _h(wt), b)
+        if j < 5:
+            y = F.leaky_relu(y, 0.2)
+            ps.append(ops.conv_params(wts, ws, h, w, cin_planes=cin // 8, out=ws, out_plane_off=pf + (j - 1) * pg, act=L.ACT_LRELU, act_param=0.2))
+            assert ps[-1].out_lo is None and ps[-1].out_fmt == PF_F16
+            cat = torch.cat((cat, _h(y)), 1)
+        else:
+            xs = tensors.planes_to_nchw(src, 64).cpu()
+            r0v = tensors.planes_to_nchw(r0src, 64).cpu()
+            ref = (y * 0.2 + xs) * 0.2 + r0v
+            ps.append(ops.conv_params(wts, ws, h, w, cin_planes=cin // 8, res1=(ws, 0), alpha=0.2, res2=(r0, 0), beta=0.2, out=out))
+            assert ps[-1].res1_lo is not None and ps[-1].out_lo is not None and ps[-1].res_fmt == PF_F16
+    assert 'one fp16 product' in L.conv_kernel_name(ps[0]) and 'one fp16 product' in L.conv_kernel_name(ps[-1])
+    ops.run_convs(ps, device)
+    torch.cuda.synchronize()
+    assert L.ring_aborts() == 0
+    got = tensors.planes_to_nchw(out, 64).cpu()
+    # (a growth value that lands on the other side of an fp16 rounding boundary than the reference's moves conv5 by 2^-11 * |w| * 0.04)
+    assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    # the growth planes hold fp16(x1..x4)
+    growth = tensors.planes_to_nchw(tensors.Planes(ws.hi[:, pf:].contiguous(), None), 128).cpu()
+    assert (growth - cat[:, 64:]).abs().max().item() <= 2.0**-10 * cat.abs().max().item()
+
+
+def test_three_fp16_products_four_tile_ring(device):
+    """The trunk convolution of the 'mixed' plan: fp16 hi + lo input (the residual stream), fp16 hi + lo weights, f32-map shortcut,
+    bf16 hi + lo output for the three-product upsampling layers behind it."""
+    n, h, w = 1, 35, 66
+    x = _rand((n, 64, h, w), 11, 2.0)
+    wt = _rand((64, 64, 3, 3), 12, 1.0 / (64 * 9) ** 0.5)
+    b = _rand((64,), 13, 0.1)
+    r = _rand((n, 64, h, w), 14)
+    xin = tensors.nchw_to_planes(x.to(device), True, PF_F16)
+    xv = tensors.planes_to_nchw(xin, 64).cpu()  # hi + lo: 22 bits
+    ref = _conv(xv, wt, b) + r
+    wts = ops.ConvWeights.from_oihw(wt, b, 3, device=device, fmt=PF_F16)
+    out = tensors.Planes.empty(n, 8, h, w, device, True, PF_BF16)
+    of32 = tensors.empty_f32map(n, 64, h, w, device)
+    p = ops.conv_params(wts, xin, h, w, res1=tensors.nchw_to_f32map(r.to(device)), alpha=1.0, out=out, out_f32=of32)
+    assert 'three fp16 products' in L.conv_kernel_name(p) and p.out_fmt == PF_BF16
+    ops.run_convs([p], device)
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    assert (tensors.f32map_to_nchw(of32, 64).cpu() - ref).abs().max().item() <= 3e-6 * scale  # lo*lo dropped: 2^-22
+    assert (tensors.planes_to_nchw(out, 64).cpu() - ref).abs().max().item() <= 2e-5 * scale  # bf16 hi + lo: 2^-16
+
+
+def test_whole_map_many_tiles_per_workgroup(device):
+    """More tiles than workgroups (each workgroup's streams run several tiles through the eight-slot ring), batch 2, against F.conv2d."""
+    n, cin, cout, h, w = 2, 96, 32, 300, 610
+    x = _rand((n, cin, h, w), 21)
+    wt = _rand((cout, cin, 3, 3), 22, 1.0 / (cin * 9) ** 0.5)
+    b = _rand((cout,), 23, 0.1)
+    ref = F.leaky_relu(F.conv2d(_h(x), _h(wt), b, padding=1), 0.2)
+    wts = ops.ConvWeights.from_oihw(wt, b, 1, device=device, fmt=PF_F16)
+    xin = tensors.nchw_to_planes(x.to(device), False, PF_F16)
+    of32 = tensors.empty_f32map(n, cout, h, w, device)
+    out = tensors.Planes.empty(n, 4, h, w, device, False, PF_F16)
+    before = L.ring_aborts()
+    for _ in range(3):
+        ops.run_convs([ops.conv_params(wts, xin, h, w, act=L.ACT_LRELU, act_param=0.2, out=out, out_f32=of32)], device)
+    torch.cuda.synchronize()
+    assert L.ring_aborts() == before
+    L.check_status('test')
+    assert (tensors.f32map_to_nchw(of32, cout).cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize('products', [1, 3])
+@pytest.mark.parametrize('layout,cin,cout,k', [(0, 40, 24, 3), (0, 240, 100, 1), (1, 64, 32, 3), (1, 192, 64, 3), (2, 48, 48, 3)])
+def test_pack_weights_fp16(device, products, layout, cin, cout, k):
+    w = _rand((cout, cin, k, k), 31, 0.3)
+    cin_planes = (cin + 7) // 8
+    got = ops.pack_weights_device(w.to(device), cin_planes, products, layout, PF_F16).view(torch.int16).cpu()
+    if layout == 0:
+        exp = pack.pack_conv_weights(w, cin_planes, products, torch.float16)
+    elif layout == 1:
+        exp = pack.pack_conv_weights_pairs(w, cin_planes, products, torch.float16)
+    else:
+        exp = pack.pack_conv_weights_halfpairs(w, cin_planes, products, torch.float16)
+    assert torch.equal(got, exp.reshape(-1).view(torch.int16))
+
+
+def test_failed_hand_off_is_an_error(device):
+    """With the spin bound forced to one poll the ring kernels drain with wrong pixels; the host-visible failure word turns that into an
+    exception at rsa_check_status and makes the next rsa_conv2d_list refuse to launch."""
+    n, cin, cout, h, w = 1, 64, 32, 128, 256
+    x = _rand((n, cin, h, w), 41)
+    wt = _rand((cout, cin, 3, 3), 42, 0.05)
+    wts = ops.ConvWeights.from_oihw(wt, None, 1, device=device, fmt=PF_F16)
+    xin = tensors.nchw_to_planes(x.to(device), False, PF_F16)
+    out = tensors.Planes.empty(n, 4, h, w, device, False, PF_F16)
+    p = ops.conv_params(wts, xin, h, w, out=out)
+    torch.cuda.synchronize()
+    L.check_status('before')
+    before = L.ring_aborts()
+    L.set_ring_spin_limit(1)
+    try:
+        ops.run_convs([p], device)
+        torch.cuda.synchronize()
+    finally:
+        L.set_ring_spin_limit(1 << 18)
+    if L.ring_aborts() == before:
+        pytest.skip('every hand-off was ready at its first poll: nothing timed out on this run')
+    with pytest.raises(RuntimeError, match='hand-off'):
+        ops.run_convs([p], device)  # refused: a failure is pending
+    with pytest.raises(RuntimeError, match='hand-off'):
+        L.check_status('forced failure')
+    L.check_status('cleared')  # reported once, then clear
+    ops.run_convs([p], device)
+    torch.cuda.synchronize()
+    L.check_status('after')

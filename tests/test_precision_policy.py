@@ -1,0 +1,61 @@
+"""The 'auto' precision policy of RRDBNet, emulated on the CPU (tests/precision_policy.py patches the oracle's convolution to round
+its operands the way the engine's kernels do): which layers may run ONE fp16 product and which need three products, pinned BEFORE any
+kernel runs.  north_star's bar is 1e-3 max-abs against CPU fp32; the engine's bar for its default mode is 2e-4.
+
+Measured here (RRDBNet-23, 128 x 128 crop of the bench frame / heavy-tailed checkpoint):
+    mixed table (RDB convolutions fp16 x 1, trunk conv fp16 x 3, conv_first / upconvs / HR / last bf16 x 3)   1.2e-4 / 8.9e-5
+    one fp16 product everywhere                                                                                1.9e-3 / 1.8e-3   (over)
+    bf16 x 3 everywhere (the conservative mode)                                                                2.6e-5 / 3.1e-5
+    RDB convolutions in one bf16 product, head / tail bf16 x 3                                                 6.8e-4 / 6.0e-4
+"""
+
+import torch
+
+import precision_policy as P
+from oracle.rrdbnet import rrdbnet_forward
+from resselt_amd.utils import synth
+
+
+def _errors(sd, x, cases):
+    with torch.no_grad():
+        ref = rrdbnet_forward(sd, x)
+        out = {}
+        for name, (policy, stream) in cases.items():
+            with P.emulate(policy, stream):
+                out[name] = (rrdbnet_forward(sd, x) - ref).abs().max().item()
+    return out
+
+
+def test_the_engine_table_is_the_emulated_table():
+    """RRDBNet.layer_policy (what _pack uses) and the emulator's table name the same arithmetic for every convolution of the network."""
+    from resselt_amd.archs.esrgan.arch import RRDBNet
+    from resselt_amd.engine.tensors import PF_BF16, PF_F16
+
+    names = {(1, PF_F16): 'fp16', (3, PF_F16): 'fp16x3', (3, PF_BF16): 'bf16x3'}
+    sd = synth.rrdbnet_state_dict(nb=2, seed=0)
+    for key in sd:
+        if key.endswith('.weight'):
+            base = key[: -len('.weight')]
+            assert names[RRDBNet.layer_policy(base)] == P.rrdbnet_auto(base), base
+    m = RRDBNet()
+    assert m.precision == 'auto' and m.resolved_precision() == 'mixed'
+    assert RRDBNet(plus=True).resolved_precision() == 'bf16x3' and RRDBNet(num_filters=32).resolved_precision() == 'bf16x3'
+
+
+def test_mixed_policy_meets_the_bar_on_rrdbnet23():
+    torch.set_num_threads(8)
+    sd = synth.rrdbnet_state_dict(nb=23, seed=0)
+    x = synth.synth_input((1, 3, 1080, 1920), seed=0)[:, :, 400:528, 800:928].contiguous()
+    e = _errors(sd, x, {'mixed': (P.rrdbnet_auto, torch.float16), 'fp16': (P.uniform('fp16'), None), 'bf16x3': (P.uniform('bf16x3'), torch.bfloat16)})
+    print(e)
+    assert e['mixed'] <= 2e-4 and e['bf16x3'] <= 1e-4
+    assert e['fp16'] > 1e-3  # one product everywhere does NOT meet north_star's bar: the reason the policy is per layer
+
+
+def test_mixed_policy_on_heavy_tailed_weights():
+    torch.set_num_threads(8)
+    sd = synth.rrdbnet_heavy_tailed_state_dict(nb=23, seed=4)
+    x = synth.synth_input((1, 3, 96, 112), seed=4)
+    e = _errors(sd, x, {'mixed': (P.rrdbnet_auto, torch.float16)})
+    print(e)
+    assert e['mixed'] <= 2e-4

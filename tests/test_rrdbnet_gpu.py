@@ -1,7 +1,8 @@
 """End-to-end GPU parity of the RRDBNet engine against (a) vectors produced by the real reference
 (tests/golden, tools/gen_golden.py) and (b) the CPU oracle on seeded inputs.
 
-Tolerances (max-abs, outputs are O(1)): bf16x3 mode 2e-4 (north_star bar: 1e-3), plain bf16 mode 6e-2.
+Tolerances (max-abs, outputs are O(1)): 'auto' (the default: residual dense blocks in one fp16 product, head / tail in three bf16
+products) and bf16x3 2e-4 (north_star bar: 1e-3), plain bf16 mode 6e-2 (a smoke bound: that mode is not a default anywhere).
 """
 
 import pytest
@@ -13,7 +14,7 @@ from resselt_amd.utils import synth
 
 pytestmark = pytest.mark.gpu
 
-TOL = {'bf16x3': 2e-4, 'bf16': 6e-2}
+TOL = {'auto': 2e-4, 'bf16x3': 2e-4, 'bf16': 6e-2}
 
 
 def _model(sd, device, precision='bf16x3'):
@@ -22,20 +23,33 @@ def _model(sd, device, precision='bf16x3'):
     return m
 
 
+@pytest.fixture(autouse=True)
+def _no_failed_hand_offs():
+    """Every model-level test ends with the ring schedule's failure word clear (rsa_check_status after a synchronise)."""
+    yield
+    from resselt_amd.engine import lib as L
+
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        L.check_status('end of test')
+
+
+@pytest.mark.parametrize('precision', ['auto', 'bf16x3'])
 @pytest.mark.parametrize('name', golden_names('rrdbnet_'))
-def test_rrdbnet_matches_reference_vectors(device, name):
+def test_rrdbnet_matches_reference_vectors(device, name, precision):
     meta, arr = load_golden(name)
     sd = synth_state_dict(meta)
-    m = _model(sd, device)
+    m = _model(sd, device, precision)
+    assert m.precision == precision and (precision != 'auto' or m.resolved_precision() in ('mixed', 'bf16x3'))
     assert vars(m.parameters_info) == {k: meta['metadata'][k] for k in ('in_channels', 'out_channels', 'upscale', 'name')}
     y = m(arr['x'].to(device))
     torch.cuda.synchronize()
     assert y.shape == arr['y'].shape and y.dtype == torch.float32
     err = (y.cpu() - arr['y']).abs().max().item()
-    assert err <= TOL['bf16x3'], f'{name}: max-abs {err:.3e}'
+    assert err <= TOL[precision], f'{name} {precision}: max-abs {err:.3e}'
 
 
-@pytest.mark.parametrize('precision', ['bf16x3', 'bf16'])
+@pytest.mark.parametrize('precision', ['auto', 'bf16x3', 'bf16'])
 def test_rrdbnet23_vs_oracle_multi_tile(device, precision):
     from oracle.rrdbnet import rrdbnet_forward
 
@@ -81,13 +95,14 @@ def test_rrdbnet_rejects_cpu_and_bad_shapes(device):
         m(torch.zeros(3, 8, 8, device=device))
 
 
-def test_rrdbnet_full_frame_tile_consistency(device):
+@pytest.mark.parametrize('precision', ['auto', 'bf16x3'])
+def test_rrdbnet_full_frame_tile_consistency(device, precision):
     """BASELINE-size property check: a 1080p frame and a halo-padded crop of it agree in the crop's interior.
 
     (Translation equivariance of the conv stack; survey-measured effective receptive field: halo 32 -> 1.5e-6.)
     """
     sd = synth.rrdbnet_state_dict(nb=23, seed=0)
-    m = _model(sd, device)
+    m = _model(sd, device, precision)
     x = synth.synth_input((1, 3, 1080, 1920), seed=0).to(device)
     y = m(x)
     assert y.shape == (1, 3, 4320, 7680)
@@ -108,7 +123,7 @@ def test_rrdbnet_tiled_driver_on_gpu(device):
     from resselt_amd.tiling import TileParallel, upscale_tiled
 
     sd = synth.rrdbnet_state_dict(nb=23, seed=1)
-    m = _model(sd, device)
+    m = _model(sd, device, 'auto')
     x = synth.synth_input((1, 3, 150, 210), seed=1).to(device)
     full = m(x)
     tiled = upscale_tiled(m, x, scale=4, tile=(80, 112), halo=40)

@@ -67,7 +67,8 @@ def _worker(rank, world, port, q):
         y = TileParallel(model, scale=2, halo=24)(x)
         y3 = TileParallel(model, scale=2, halo=24, grid=(3, 1))(x)  # 3 uneven tiles on 2 ranks: round-robin + padding
         y1 = TileParallel(model, scale=2, halo=24, grid=(1, 1))(x)  # fewer tiles than ranks: rank 1 idles but joins the collective
-        q.put((rank, y, y3, y1))
+        # by value (numpy): a torch tensor goes through the queue as a file descriptor its producer must outlive
+        q.put((rank, y.numpy(), y3.numpy(), y1.numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -87,7 +88,7 @@ def test_tile_parallel_all_gather_gloo(world):
     results = dict()
     for _ in range(world):
         rank, y, y3, y1 = q.get(timeout=180)
-        results[rank] = (y.clone(), y3.clone(), y1.clone())
+        results[rank] = (torch.from_numpy(y), torch.from_numpy(y3), torch.from_numpy(y1))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
