@@ -189,7 +189,8 @@ int rsa_pack_weights(const float* w_oihw, int32_t cout, int32_t cin, int32_t cin
 /* Name of the kernel a descriptor dispatches to (matches the rocprofv3 kernel names; bench.py groups its rooflines by it). */
 const char* rsa_conv_kernel_name(const rsa_conv_params* p);
 
-/* Debug: spins of the ring schedule's LDS hand-offs that ran into their bound (always 0 in a correct build; tests assert it). */
+/* Debug: hand-offs of the ring schedule that ran into their spin bound since the last call (always 0 in a correct build; tests assert it).
+ * Synchronises the device (unlike rsa_check_status, which is the product's way to learn of the same event). */
 int rsa_debug_ring_aborts(void);
 /* Debug: polls a hand-off of the ring schedule may spend before it gives up (default 2^18; 1 forces the failure path: tests). */
 int rsa_debug_set_ring_spin_limit(int32_t polls);

@@ -11,11 +11,16 @@ import torch
 
 from ...engine import lib as L
 from ...engine import ops
-from ...engine.base import EngineModule, Plan
+from ...engine.base import EngineModule, Plan, check_fp16_range
 from ...engine.paramtree import build_param_tree
 
 
 class SRVGGNetCompact(EngineModule):
+    # 'fp16' (what 'auto' selects): every convolution in ONE fp16 product on hi planes -- the reference's own fp16 inference arithmetic with an
+    # f32 accumulator.  Pinned at <= half an fp16 ulp of the output + 1e-4 by tests/test_baseline_configs_gpu.py (C3) and test_span_gpu.py.
+    auto_precision = 'fp16'
+    precisions = ('bf16x3', 'bf16', 'fp16')
+
     def __init__(self, num_in_ch=3, num_out_ch=3, num_feat=64, num_conv=16, upscale=4, act_type='prelu'):
         super().__init__()
         if act_type != 'prelu':
@@ -43,6 +48,7 @@ class SRVGGNetCompact(EngineModule):
             W[f'body.{2 * i}'] = ops.ConvWeights.from_oihw(sd[f'body.{2 * i}.weight'], sd[f'body.{2 * i}.bias'], products, device=device)
             W[f'slope.{2 * i + 1}'] = ops.pad_bias(sd[f'body.{2 * i + 1}.weight'], self.num_feat, device)
         W[f'body.{self._last}'] = ops.ConvWeights.from_oihw(sd[f'body.{self._last}.weight'], sd[f'body.{self._last}.bias'], products, device=device)
+        check_fp16_range(W.values())
         return W
 
     def macs_per_input_pixel(self) -> int:

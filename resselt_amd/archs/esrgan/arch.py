@@ -19,7 +19,7 @@ import torch
 
 from ...engine import lib as L
 from ...engine import ops
-from ...engine.base import EngineModule, Fp16Range, Plan
+from ...engine.base import EngineModule, Plan, check_fp16_range
 from ...engine.tensors import PF_BF16, PF_F16
 from ...engine.paramtree import build_param_tree
 
@@ -153,16 +153,12 @@ class RRDBNet(EngineModule):
         if mixed and self.plus:
             raise NotImplementedError("ESRGAN+ (conv1x1 branch) has no 'mixed' plan; use precision = 'bf16x3'")
         out = {}
-        amax = []
         for name in sd:
             if name.endswith('.weight'):
                 base = name[: -len('.weight')]
                 prod, fmt = self.layer_policy(base) if mixed else (int(products), products.fmt)
                 out[base] = ops.ConvWeights.from_oihw(sd[name], sd.get(f'{base}.bias'), prod, device=device, fmt=fmt)
-                if fmt == PF_F16:
-                    amax.append(out[base].w.abs().amax())
-        if amax and float(torch.stack(amax).amax()) > 6.0e4:  # one synchronisation per pack: the fp16 range guard
-            raise Fp16Range('a convolution weight exceeds the fp16 range (|w| > 6e4)')
+        check_fp16_range(out.values())
         return out
 
     # ---------------------------------------------------------------- plan

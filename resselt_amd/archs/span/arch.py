@@ -8,10 +8,15 @@ from ...engine import lib as L
 from ...engine import ops
 from ...engine.base import EngineModule, Plan
 from ...engine.paramtree import build_param_tree
-from ...engine.spanblocks import SpabChain, conv3xc_shapes, pack_span_family, spab_shapes
+from ...engine.spanblocks import SPAN_MIXED, SpabChain, conv3xc_shapes, pack_span_family, spab_shapes
 
 
 class SPAN(EngineModule):
+    # 'mixed' (what 'auto' selects; engine/spanblocks.py::SPAN_MIXED): the re-parameterised 3x3 convolutions in ONE fp16 product on hi planes,
+    # conv_cat and the upsampler head in three fp16 products on hi + lo planes.  'fp16' = one product everywhere (2e-4: a benchmark mode).
+    auto_precision = 'mixed'
+    precisions = ('bf16x3', 'bf16', 'fp16', 'mixed')
+    precision_table = SPAN_MIXED
     hyperparameters = {}
 
     def __init__(self, *, num_in_ch: int, num_out_ch: int, feature_channels: int = 48, upscale: int = 4, norm: bool = True,
@@ -54,8 +59,9 @@ class SPAN(EngineModule):
             raise RuntimeError('SPAN input normalisation needs a 3-channel input')
         fc, pf, s = self.fc, self.fc // 8, self.upscale
         with_lo = products == 3
-        x_pl = plan.planes(n, (c + 7) // 8, h, w, with_lo)
-        chain = SpabChain(plan, W, n, h, w, fc, L.ACT_SILU, with_lo)
+        wide = with_lo or products.name == 'mixed'  # buffers read by a three-product layer (conv_cat, the head) keep hi + lo
+        x_pl = plan.planes(n, (c + 7) // 8, h, w, wide)
+        chain = SpabChain(plan, W, n, h, w, fc, L.ACT_SILU, with_lo, cat_lo=wide)
         mean = W['mean'] if self.is_norm else None
         scale = self.img_range if self.is_norm else 1.0
 
@@ -65,7 +71,7 @@ class SPAN(EngineModule):
 
         cat = chain.new_cat()
         xf = plan.f32map(n, fc, h, w)
-        feat = plan.planes(n, pf, h, w, with_lo)
+        feat = plan.planes(n, pf, h, w, wide)
         plan.conv(ops.conv_params(W['conv_1'], x_pl, h, w, out=cat, out_plane_off=0, out_f32=xf))
         names = dict(first='block_1', middle=[f'block_{i}' for i in range(2, 6)], end='block_6', conv_2='conv_2', conv_cat='conv_cat')
         chain.run(names, cat, xf, feat, 0, None)

@@ -10,7 +10,7 @@ from ...engine import lib as L
 from ...engine import ops
 from ...engine.base import EngineModule, Plan
 from ...engine.paramtree import build_param_tree
-from ...engine.spanblocks import SpabChain, conv3xc_shapes, pack_span_family, spab_shapes
+from ...engine.spanblocks import SPAN_MIXED, SpabChain, conv3xc_shapes, pack_span_family, spab_shapes
 
 _GROUPS = 4  # DySample groups, fixed by the reference (utilities/dysample.py:17)
 
@@ -22,6 +22,11 @@ def dysample_init_pos(scale: int, groups: int = _GROUPS) -> torch.Tensor:
 
 
 class SpanPlus(EngineModule):
+    # 'mixed' (what 'auto' selects; engine/spanblocks.py::SPAN_MIXED): the re-parameterised 3x3 convolutions in ONE fp16 product on hi planes,
+    # conv_cat and the upsampler head in three fp16 products on hi + lo planes.  'fp16' = one product everywhere (2e-4: a benchmark mode).
+    auto_precision = 'mixed'
+    precisions = ('bf16x3', 'bf16', 'fp16', 'mixed')
+    precision_table = SPAN_MIXED
     def __init__(self, num_in_ch: int = 3, num_out_ch: int = 3, blocks=(4,), feature_channels: int = 48, upscale: int = 4,
                  drop_rate: float = 0.0, upsampler: str = 'dys') -> None:  # fmt: skip
         super().__init__()
@@ -90,7 +95,8 @@ class SpanPlus(EngineModule):
             # offset (with bias) and scope (no bias) 1x1 convs as ONE k1 convolution: channels [0,oc) | [oc,2oc)
             w = torch.cat([sd['upsampler.offset.weight'], sd['upsampler.scope.weight']], 0)
             b = torch.cat([sd['upsampler.offset.bias'], torch.zeros_like(sd['upsampler.offset.bias'])], 0)
-            W['upsampler.offscope'] = ops.ConvWeights.from_oihw(w, b, products, device=device)
+            head = dict(products=3, fmt=1) if products.name == 'mixed' else dict(products=products)  # the head reads hi + lo planes (spanblocks.SPAN_MIXED)
+            W['upsampler.offscope'] = ops.ConvWeights.from_oihw(w, b, device=device, **head)
             end_w = sd['upsampler.end_conv.weight'].reshape(self.out_ch, self.fc)
             if self.out_ch <= 4:
                 # bilinear sampling is linear: the 1x1 end conv is applied per channel group BEFORE the sampling, at low resolution
@@ -99,7 +105,7 @@ class SpanPlus(EngineModule):
                 wz = torch.zeros((4 * _GROUPS, self.fc), dtype=torch.float32, device=device)
                 for g in range(_GROUPS):
                     wz[4 * g : 4 * g + self.out_ch, g * cpg : (g + 1) * cpg] = end_w[:, g * cpg : (g + 1) * cpg]
-                W['upsampler.zproj'] = ops.ConvWeights.from_oihw(wz[:, :, None, None], None, products, device=device)
+                W['upsampler.zproj'] = ops.ConvWeights.from_oihw(wz[:, :, None, None], None, device=device, **head)
             W['dys'] = dict(
                 init_pos=sd['upsampler.init_pos'].reshape(-1).contiguous(),
                 end_w=sd['upsampler.end_conv.weight'].reshape(self.out_ch, self.fc).contiguous(),
@@ -124,8 +130,9 @@ class SpanPlus(EngineModule):
             raise RuntimeError(f'model expects {self.in_ch} input channels, got {c}')
         fc, pf, s = self.fc, self.fc // 8, self.upscale
         with_lo = products == 3
-        x_pl = plan.planes(n, (c + 7) // 8, h, w, with_lo)
-        chain = SpabChain(plan, W, n, h, w, fc, L.ACT_MISH, with_lo)
+        wide = with_lo or products.name == 'mixed'  # buffers read by a three-product layer (conv_cat, the head) keep hi + lo
+        x_pl = plan.planes(n, (c + 7) // 8, h, w, wide)
+        chain = SpabChain(plan, W, n, h, w, fc, L.ACT_MISH, with_lo, cat_lo=wide)
         preproj = self.upsampler_kind == 'dys' and 'upsampler.zproj' in W
         need_f32_feat = self.upsampler_kind == 'dys' and not preproj
 
@@ -134,7 +141,7 @@ class SpanPlus(EngineModule):
 
         # feats.0 -> slot 0 of the first cat buffer (or straight to the upsampler input when there is no SPABS)
         nb = len(self.blocks)
-        feat = plan.planes(n, pf, h, w, with_lo)
+        feat = plan.planes(n, pf, h, w, wide)
         feat_f32 = plan.f32map(n, fc, h, w) if need_f32_feat else None
         xf = [plan.f32map(n, fc, h, w) for _ in range(2)]
         if nb == 0:

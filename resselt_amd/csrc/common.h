@@ -25,15 +25,14 @@ enum { RSA_WL_TAPS = 0, RSA_WL_PAIRS = 1, RSA_WL_HALFPAIRS = 2, RSA_WL_UPPHASE =
 // with three cout tiles (the 48 -> 48 layers of the SPAN family: half mode).  RSA_CONV_RING=0 in the environment switches the schedule off (A/B runs).
 bool conv_ring_enabled();
 void conv_ring_override(int v);
-// Round 3: the same schedule in ONE product on fp16 hi planes (every shape, no fused upsampling), and in three fp16 products for the
-// four-tile shape (the trunk convolution of RRDBNet under the 'auto' precision policy reads the fp16 residual stream).
+// Round 3: the same schedule in ONE product on fp16 hi planes and in three fp16 products on fp16 split planes (every shape, no fused
+// upsampling): the residual dense blocks / the trunk convolution of RRDBNet and the SPAN family under their 'auto' precision policies.
 inline bool conv_ring_eligible(const rsa_conv_params& p) {
   const int ct = (p.cout + 15) / 16;
   if (p.ksize != 3 || p.cin_planes < 2 || (p.cin_planes & 1)) return false;
   const bool whole = (p.cin_planes & 3) == 0;
-  if (p.products == 3 && p.in_fmt == RSA_PF_F16) return whole && ct == 4 && !p.upsample2x && p.out_nchw == nullptr;
   if (p.products == 1 && p.in_fmt != RSA_PF_F16) return false;  // plain-bf16 mode stays on the chunk-barrier kernels
-  if (p.products == 1 && p.upsample2x) return false;
+  if (p.in_fmt == RSA_PF_F16 && p.upsample2x) return false;      // fp16 planes: no fused upsampling instantiated
   if (p.out_nchw != nullptr) return ct == 3 && !p.upsample2x;  // final stores: the three-tile shape only (the pixel-shuffle heads of SPAN / Compact)
   if (whole) return ct == 2 || ct == 4 || (ct == 3 && !p.upsample2x);
   return ct == 3 && !p.upsample2x;

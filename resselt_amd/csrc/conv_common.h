@@ -201,7 +201,7 @@ struct GeoLW {
 // registers (the descriptor is ~80 SGPRs: 130 of the 770 instructions of one generic iteration were SGPR spill reloads).  The two
 // shapes that make up an RRDBNet frame are compiled again with those tests folded:
 //   EM 1: split-plane output only (hi and lo), no residual, no f32 map, no PReLU      -- the growth convolutions (276 of 351 launches)
-//   EM 2: EM 1 + residual 1 as split planes (hi + lo) and an optional residual 2 as split planes -- conv5 of a residual dense block
+//   EM 2: EM 1 + residual 1 as split planes (hi + lo) -- conv5 of a residual dense block;   EM 3: EM 2 + residual 2 (the RRDB's)
 // PF = plane format of the outputs and residuals of EM 1 / 2 (the generic body reads p.out_fmt / p.res_fmt).  With PF = fp16, EM 1
 // writes hi ONLY (the one-product consumers never read lo); EM 2 keeps hi + lo (the residual stream: 22 bits).
 template <int NCT, int CTW, int NPT, int OUTK, int AC, int EM = 0, int PF = 0>
@@ -210,10 +210,11 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
   constexpr int RPW = NPT / 2;
   constexpr bool G = EM == 0;
   const bool R1F = G && p.res1 != nullptr, R2F = G && p.res2 != nullptr;                          // residuals as f32 maps
-  const bool R1P = G ? p.res1_hi != nullptr : EM == 2, R2P = G ? p.res2_hi != nullptr : (EM == 2 && p.res2_hi != nullptr);  // as planes
+  const bool R1P = G ? p.res1_hi != nullptr : EM >= 2, R2P = G ? p.res2_hi != nullptr : EM == 3;  // as planes
   const bool R1L = G ? p.res1_lo != nullptr : true, R2L = G ? p.res2_lo != nullptr : true;       // ... with lo planes
   const bool OF32 = G && p.out_f32 != nullptr;
   const bool OHI = G ? p.out_hi != nullptr : true, OLO = G ? p.out_lo != nullptr : !(EM == 1 && PF == RSA_PF_F16);
+  static_assert(EM >= 0 && EM <= 3, "epilogue shape");
   const bool OF16 = G ? p.out_fmt == RSA_PF_F16 : PF == RSA_PF_F16;  // plane format of the outputs / of the plane residuals
   const bool RF16 = G ? p.res_fmt == RSA_PF_F16 : PF == RSA_PF_F16;
   const bool PRELU = G && p.act == RSA_ACT_PRELU;
@@ -299,7 +300,44 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
       }
     }
   };
-  if (OUTK == 0 && EM != 1) fetch_res(0, 0);
+  // EM 2 (plane residuals of a residual dense block's conv5): the residual halves are fetched PD steps ahead in raw form.  One step
+  // ahead left every one of the 8 steps of a tile waiting for a full memory latency (the one-product multiply of a tile is as long as
+  // those eight waits: profiles/r03_b); PD steps in flight cost (PD + 1) * 8 (16 with a second residual) registers, free after the K loop.
+#ifndef RSA_EPI_PD
+#define RSA_EPI_PD 3
+#endif
+  constexpr int PD = EM == 2 ? RSA_EPI_PD : (EM == 3 ? (RSA_EPI_PD + 1) / 2 : 0);
+  constexpr int NSTEPS_E = CTW * RPW;
+  uint2 rb1h[PD + 1][2], rb1l[PD + 1][2], rb2h[EM == 3 ? PD + 1 : 1][2], rb2l[EM == 3 ? PD + 1 : 1][2];
+  auto fetch_raw = [&](int s) {
+    const int ct = s / RPW, pp = s % RPW, slot = s % (PD + 1);
+    const int cbase = (ctile0 + ct) * 16;
+    const int c0 = cbase + lg * 4;
+    const bool cok = (wct * CTW + ct < NCT) && c0 < cout8;
+    const int64_t runit0 = (int64_t)n * p.res_batch_stride + (int64_t)(cbase >> 3) * p.res_plane_stride + pix0;
+    const uint32_t rlane = (uint32_t)(lg >> 1) * (uint32_t)p.res_plane_stride;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int pt = pp * 2 + e;
+      const bool okl = pvalid_of(pt) && cok;
+      const uint32_t poff = (rlane + lpix_of(pt)) * 16u + (uint32_t)(lg & 1) * 8u;
+      rb1h[slot][e] = rb1l[slot][e] = make_uint2(0u, 0u);
+      if (EM == 3) rb2h[slot][e] = rb2l[slot][e] = make_uint2(0u, 0u);
+      if (okl) {
+        rb1h[slot][e] = *(const uint2*)((const char*)p.res1_hi + runit0 * 16 + poff);
+        rb1l[slot][e] = *(const uint2*)((const char*)p.res1_lo + runit0 * 16 + poff);
+        if (EM == 3) {
+          rb2h[slot][e] = *(const uint2*)((const char*)p.res2_hi + runit0 * 16 + poff);
+          rb2l[slot][e] = *(const uint2*)((const char*)p.res2_lo + runit0 * 16 + poff);
+        }
+      }
+    }
+  };
+  if (OUTK == 0 && EM == 0) fetch_res(0, 0);
+  if (OUTK == 0 && EM >= 2) {
+#pragma unroll
+    for (int s = 0; s < PD && s < NSTEPS_E; ++s) fetch_raw(s);
+  }
 
 #pragma unroll
   for (int ct = 0; ct < CTW; ++ct) {
@@ -329,12 +367,22 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
       bool ok[2];
       f32x4 cr1[2], cr2[2];
       if (OUTK == 0) {
+        if (EM >= 2) {
+          const int s = ct * RPW + pp;
+          if (s + PD < NSTEPS_E) fetch_raw(s + PD);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          cr1[e] = nr1[e];
-          cr2[e] = nr2[e];
+          for (int e = 0; e < 2; ++e) {
+            cr1[e] = widen(rb1h[s % (PD + 1)][e], rb1l[s % (PD + 1)][e]);
+            cr2[e] = EM == 3 ? widen(rb2h[EM == 3 ? s % (PD + 1) : 0][e], rb2l[EM == 3 ? s % (PD + 1) : 0][e]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            cr1[e] = nr1[e];
+            cr2[e] = nr2[e];
+          }
         }
-        if (EM == 1) {
+        if (EM != 0) {
         } else if (pp + 1 < RPW)
           fetch_res(ct, pp + 1);
         else if (ct + 1 < CTW)
@@ -542,14 +590,18 @@ __device__ __forceinline__ void epilogue(const rsa_conv_params& p, const f32x4 (
           (p.cout & 15) == 0 && (p.act == RSA_ACT_NONE || (p.act_param >= 0.f && p.act_param <= 1.f))) {
         // the two shapes of an RRDBNet frame, with the descriptor tests folded (see EM above); wave-uniform choice
         const bool planes_res = p.res1_hi != nullptr && p.res1_lo != nullptr && (p.res2_hi == nullptr || p.res2_lo != nullptr);
+        const bool two = p.res2_hi != nullptr;
         if (p.out_fmt == RSA_PF_BF16 && p.out_lo != nullptr) {
           if (p.res1_hi == nullptr && p.res2_hi == nullptr) return epilogue_impl<NCT, CTW, NPT, OUTK, AC_LINEAR, 1>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
-          if (planes_res && p.res_fmt == RSA_PF_BF16) return epilogue_impl<NCT, CTW, NPT, OUTK, AC_LINEAR, 2>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
+          if (planes_res && p.res_fmt == RSA_PF_BF16)
+            return two ? epilogue_impl<NCT, CTW, NPT, OUTK, AC_LINEAR, 3>(p, acc, n, y0, x0, slab, wct, wpx, li, lg)
+                       : epilogue_impl<NCT, CTW, NPT, OUTK, AC_LINEAR, 2>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
         } else if (p.out_fmt == RSA_PF_F16) {
           if (p.out_lo == nullptr && p.res1_hi == nullptr && p.res2_hi == nullptr)
             return epilogue_impl<NCT, CTW, NPT, OUTK, AC_LINEAR, 1, RSA_PF_F16>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
           if (p.out_lo != nullptr && planes_res && p.res_fmt == RSA_PF_F16)
-            return epilogue_impl<NCT, CTW, NPT, OUTK, AC_LINEAR, 2, RSA_PF_F16>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
+            return two ? epilogue_impl<NCT, CTW, NPT, OUTK, AC_LINEAR, 3, RSA_PF_F16>(p, acc, n, y0, x0, slab, wct, wpx, li, lg)
+                       : epilogue_impl<NCT, CTW, NPT, OUTK, AC_LINEAR, 2, RSA_PF_F16>(p, acc, n, y0, x0, slab, wct, wpx, li, lg);
         }
       }
 #endif

@@ -3,6 +3,11 @@
 #include "conv_ring.h"
 
 namespace rsa {
-int conv_launch_ring2_f16(const rsa_conv_params& p, hipStream_t stream) { return launch_ring<2, 0, 0, 0, RSA_PF_F16, 1>(p, stream); }
+int conv_launch_ring2_f16(const rsa_conv_params& p, hipStream_t stream) {
+  return p.products == 1 ? launch_ring<2, 0, 0, 0, RSA_PF_F16, 1>(p, stream) : launch_ring<2, 0, 0, 0, RSA_PF_F16, 3>(p, stream);
+}
 unsigned int conv_ring2h_aborts() { return ring_aborts_this_unit(); }
+#ifdef RSA_RING_DEBUG
+int conv_ring2h_set_dbg(unsigned v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_ring_dbg), &v, sizeof(v)) == hipSuccess ? 0 : -1; }
+#endif
 }  // namespace rsa

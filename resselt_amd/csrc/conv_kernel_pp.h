@@ -23,7 +23,7 @@
 
 namespace rsa {
 
-template <int KS, int PROD, int UP, int OUTK>
+template <int KS, int PROD, int UP, int OUTK, int FMT = 0>
 __global__ __launch_bounds__(576, 3) void conv_kernel_pp(const rsa_conv_params p) {
   using G = GeoLW<KS, 4>;  // per-wave shape: CTW = 2 cout tiles, NPT = 8 pixel tiles, 4 row groups
   constexpr int TH = G::TH, TW = G::TW, HALO = G::HALO, IH = G::IH, IW = G::IW, PS = G::PS;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(576, 3) void conv_kernel_pp(const rsa_conv_params p
               // products in increasing magnitude: w_lo*a_hi, w_hi*a_lo, w_hi*a_hi
               const bf16x8 wf = (PROD == 3 && pr == 0) ? wc[ct][NHL - 1] : wc[ct][0];
               const bf16x8 bf = (PROD == 3 && pr == 1) ? rl[i % (LDS_DEPTH + 1)] : rh[i % (LDS_DEPTH + 1)];
-              acc[sp][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, bf, acc[sp][ct], 0, 0, 0);
+              acc[sp][ct] = mfma16<FMT>(wf, bf, acc[sp][ct]);
             }
           if (i + LDS_DEPTH < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, NHL, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, NPR * CTW, 0);
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(576, 3) void conv_kernel_pp(const rsa_conv_params p
   }
 }
 
-template <int KS, int PROD, int UP, int OUTK>
+template <int KS, int PROD, int UP, int OUTK, int FMT = 0>
 static int launch_pp(const rsa_conv_params& p, hipStream_t stream) {
   using G = GeoLW<KS, 4>;
   const int tiles_x = (p.W + G::TW - 1) / G::TW;
@@ -242,14 +242,14 @@ static int launch_pp(const rsa_conv_params& p, hipStream_t stream) {
   if (resident == 0) {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_kernel_pp<KS, PROD, UP, OUTK>, 576, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_kernel_pp<KS, PROD, UP, OUTK, FMT>, 576, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipGetLastError();
     resident = per_cu * prop.multiProcessorCount;
     resident_cache.store(resident, std::memory_order_relaxed);
   }
   int gx = resident;
   if (gx > num_tiles) gx = (int)num_tiles;
-  hipLaunchKernelGGL((conv_kernel_pp<KS, PROD, UP, OUTK>), dim3((unsigned)gx, 1, 1), dim3(576), 0, stream, p);
+  hipLaunchKernelGGL((conv_kernel_pp<KS, PROD, UP, OUTK, FMT>), dim3((unsigned)gx, 1, 1), dim3(576), 0, stream, p);
   return (int)hipGetLastError();
 }
 
@@ -257,7 +257,7 @@ static int launch_pp(const rsa_conv_params& p, hipStream_t stream) {
 // schedule, everything else conv_kernel.  Single-product layers stay on conv_kernel: their multiply phase is a third as long, the
 // phases are then paced by the (serialised) fills, and the alternation measured 5 % slower (125.6 vs 119.3 ms per frame in plain
 // bf16 mode).  RSA_CONV_PP=0 in the environment switches it off (A/B runs).
-template <int KS, int PROD, int UP>
+template <int KS, int PROD, int UP, int FMT = 0>
 static int launch_nct_pp(const rsa_conv_params& p, int nct, hipStream_t stream) {
   static const bool use_pp = [] {
     const char* e = getenv("RSA_CONV_PP");
@@ -265,10 +265,10 @@ static int launch_nct_pp(const rsa_conv_params& p, int nct, hipStream_t stream) 
   }();
   if constexpr (KS == 3 && PROD == 3) {
     if (nct == 2 && p.cout <= 32 && use_pp) {
-      return p.out_nchw != nullptr ? launch_pp<KS, PROD, UP, 1>(p, stream) : launch_pp<KS, PROD, UP, 0>(p, stream);
+      return p.out_nchw != nullptr ? launch_pp<KS, PROD, UP, 1, FMT>(p, stream) : launch_pp<KS, PROD, UP, 0, FMT>(p, stream);
     }
   }
-  return launch_nct<KS, PROD, UP>(p, nct, stream);
+  return launch_nct<KS, PROD, UP, FMT>(p, nct, stream);
 }
 
 }  // namespace rsa

@@ -22,6 +22,8 @@ int conv_launch_k3p1u1(const rsa_conv_params& p, int nct, hipStream_t stream);
 int conv_launch_k3p1u0_f16(const rsa_conv_params& p, int nct, hipStream_t stream);
 int conv_launch_k3p1u1_f16(const rsa_conv_params& p, int nct, hipStream_t stream);
 int conv_launch_k1p1_f16(const rsa_conv_params& p, int nct, hipStream_t stream);
+int conv_launch_k3p3u0_f16(const rsa_conv_params& p, int nct, hipStream_t stream);
+int conv_launch_k1p3_f16(const rsa_conv_params& p, int nct, hipStream_t stream);
 int conv_launch_k1p3(const rsa_conv_params& p, int nct, hipStream_t stream);
 int conv_launch_k1p1(const rsa_conv_params& p, int nct, hipStream_t stream);
 
@@ -91,7 +93,8 @@ const char* conv_kernel_name(const rsa_conv_params& p) {
     const int ct = (p.cout + 15) >> 4;
     if (p.products == 1)
       return ct == 2 ? "rsa::conv_ring<2,0,0,0,f16,1> (Cout<=32, one fp16 product)" : ct == 3 ? (p.out_nchw != nullptr ? "rsa::conv_ring<3,0,1,HM,f16,1> (Cout 33..48, final store, one fp16 product)" : "rsa::conv_ring<3,0,0,HM,f16,1> (Cout 33..48, one fp16 product)") : "rsa::conv_ring<1,0,0,0,f16,1> (Cout 49..64, one fp16 product)";
-    if (p.in_fmt == RSA_PF_F16) return "rsa::conv_ring<1,0,0,0,f16,3> (Cout 49..64, three fp16 products)";
+    if (p.in_fmt == RSA_PF_F16)
+      return ct == 2 ? "rsa::conv_ring<2,0,0,0,f16,3> (Cout<=32, three fp16 products)" : ct == 3 ? (p.out_nchw != nullptr ? "rsa::conv_ring<3,0,1,HM,f16,3> (Cout 33..48, final store, three fp16 products)" : "rsa::conv_ring<3,0,0,HM,f16,3> (Cout 33..48, three fp16 products)") : "rsa::conv_ring<1,0,0,0,f16,3> (Cout 49..64, three fp16 products)";
     return ct == 2 ? "rsa::conv_ring<2,UP,0> (Cout<=32)" : ct == 3 ? (p.out_nchw != nullptr ? "rsa::conv_ring<3,0,1,HM> (Cout 33..48, final store)" : "rsa::conv_ring<3,0,0,HM> (Cout 33..48)") : "rsa::conv_ring<1,UP,0> (Cout 49..64)";
   }
   if (p.ksize == 1 && p.cout >= 96 && p.out_nchw == nullptr) return "rsa::gemm_k1_kernel";
@@ -154,22 +157,26 @@ int conv_launch(const rsa_conv_params& p, hipStream_t stream) {
     const int rc = conv_launch_ring(p, stream);
     return rc ? set_error(rc, "conv: ring kernel launch failed") : RSA_OK;
   }
-  if (p.in_fmt == RSA_PF_F16 && p.products == 3)
-    return set_error(RSA_E_UNSUPPORTED, "conv: three fp16 products exist for 3x3 layers with whole 32-channel chunks and 49..64 output channels only");
+  if (p.in_fmt == RSA_PF_F16 && p.products == 3 && p.upsample2x)
+    return set_error(RSA_E_UNSUPPORTED, "conv: three fp16 products are not compiled with a fused x2 upsampling (use bf16 planes for that layer)");
   if (p.ksize == 1) {  // wide k1 layers (nn.Linear over tokens): weight-stationary GEMM schedule, gemm_k1.hip
     const int g = gemm_k1_launch(p, stream);
     if (g != -100) return g == 0 ? RSA_OK : set_error(g, "conv: gemm_k1 launch failed");
   }
   const int nct = conv_nct(p.cout);
-  const bool f16 = p.in_fmt == RSA_PF_F16;  // one product here
+  const bool f16 = p.in_fmt == RSA_PF_F16;
   int rc;
   if (p.ksize == 3) {
     if (p.upsample2x)
       rc = (p.products == 3) ? conv_launch_k3p3u1(p, nct, stream) : f16 ? conv_launch_k3p1u1_f16(p, nct, stream) : conv_launch_k3p1u1(p, nct, stream);
+    else if (p.products == 3)
+      rc = f16 ? conv_launch_k3p3u0_f16(p, nct, stream) : conv_launch_k3p3u0(p, nct, stream);
     else
-      rc = (p.products == 3) ? conv_launch_k3p3u0(p, nct, stream) : f16 ? conv_launch_k3p1u0_f16(p, nct, stream) : conv_launch_k3p1u0(p, nct, stream);
+      rc = f16 ? conv_launch_k3p1u0_f16(p, nct, stream) : conv_launch_k3p1u0(p, nct, stream);
+  } else if (p.products == 3) {
+    rc = f16 ? conv_launch_k1p3_f16(p, nct, stream) : conv_launch_k1p3(p, nct, stream);
   } else {
-    rc = (p.products == 3) ? conv_launch_k1p3(p, nct, stream) : f16 ? conv_launch_k1p1_f16(p, nct, stream) : conv_launch_k1p1(p, nct, stream);
+    rc = f16 ? conv_launch_k1p1_f16(p, nct, stream) : conv_launch_k1p1(p, nct, stream);
   }
   if (rc != 0) return set_error(rc, "conv: kernel launch failed");
   return RSA_OK;

@@ -52,13 +52,26 @@ static __device__ unsigned int g_ring_dbg;
 static __device__ unsigned int g_ring_aborts;  // spins that ran into their bound (a protocol bug): never non-zero in a correct build
 // (one counter per translation unit that instantiates the schedule; conv_ring_aborts() adds them up)
 
-static unsigned int ring_aborts_this_unit() {
+static unsigned int ring_aborts_this_unit() {  // reads AND clears (rsa_debug_ring_aborts: "since the last call")
   unsigned int v = 0;
+  const unsigned int zero = 0;
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ring_aborts), sizeof(v)) != hipSuccess) return 0x10000000u;
+  if (v != 0 && hipMemcpyToSymbol(HIP_SYMBOL(g_ring_aborts), &zero, sizeof(zero)) != hipSuccess) return 0x10000000u;
   return v;
 }
 
 typedef const __attribute__((address_space(1))) char* gcptr;
+
+// tuning knobs of the one-product instantiations (variant builds override them: tools/variant.sh)
+#ifndef RSA_RING_INFL1
+#define RSA_RING_INFL1 2  // fills left in flight behind the one being published
+#endif
+#ifndef RSA_RING_WD1
+#define RSA_RING_WD1 3  // K steps of weight prefetch (2 -> 3: -1.7 % on the RRDBNet frame, profiles/r03_b)
+#endif
+#ifndef RSA_RING_DEPTH1
+#define RSA_RING_DEPTH1 4  // pixel-tile steps of LDS fragment prefetch
+#endif
 
 template <int PROD>
 struct RingGeoP {
@@ -70,7 +83,7 @@ struct RingGeoP {
   static constexpr int NSLOT = PROD == 3 ? 4 : 8;
   static constexpr int DMA_IT = (HALF + 63) / 64;  // 20 LDS-DMA instructions per precision; the last one covers 32 units
   static constexpr int DPF = NHL * DMA_IT;   // LDS-DMA instructions per fill
-  static constexpr int INFL = PROD == 3 ? 1 : 2;  // fills left in flight behind the one being published (INFL * DPF <= 63: vmcnt)
+  static constexpr int INFL = PROD == 3 ? 1 : RSA_RING_INFL1;  // fills left in flight behind the one being published (INFL * DPF <= 63: vmcnt)
   static constexpr int BAND = 4;             // tile rows per band of the tile order
   static constexpr int FLAG_UNITS = 5;       // uint4s behind the ring: FULL[8], FREE[8], abort
 };
@@ -288,7 +301,7 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
 
   // weights: per (chunk, K step 0..8, cout tile, hi|lo) one 1 KiB A fragment, streamed from L2 WD K steps ahead
   constexpr int KSU = HM ? 5 : 9;  // K steps per unit
-  constexpr int WD = PROD == 3 ? 1 : 2;  // K steps of weight prefetch (a one-product K step is 16 MFMAs = 256 cycles: less than an L2 hit under load)
+  constexpr int WD = PROD == 3 ? 1 : RSA_RING_WD1;  // K steps of weight prefetch (a one-product K step is 16 MFMAs = 256 cycles: less than an L2 hit under load)
   const int nks = nq * KSU;
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_packed, 0, (uint32_t)((int64_t)nks * ct_total * NHL * 64 * 16), 0x00020000);
   uint32_t woff[CTW];
@@ -379,7 +392,7 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
       asm volatile("" ::: "memory");
 
       constexpr int NSTEP = KSU * NPT;  // K steps x pixel tiles of one unit
-      constexpr int DEPTH = PROD == 3 ? 2 : 4;  // pixel-tile steps of LDS prefetch (a one-product step is CTW MFMAs = 32-48 cycles)
+      constexpr int DEPTH = PROD == 3 ? 2 : RSA_RING_DEPTH1;  // pixel-tile steps of LDS prefetch (a one-product step is CTW MFMAs = 32-48 cycles)
       bf16x8 rh[DEPTH + 1], rl[PROD == 3 ? DEPTH + 1 : 1];
       auto frag = [&](int i) -> int {  // unit of pixel-tile step i (compile-time i)
         const int ks = i / NPT, pt = i % NPT;

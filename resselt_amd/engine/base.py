@@ -30,10 +30,11 @@ PRECISIONS = {'bf16x3': (3, PF_BF16), 'bf16': (1, PF_BF16), 'fp16': (1, PF_F16),
 
 
 class Prec(int):
-    """``products`` (1 or 3; this IS the int, so architecture code written against an int keeps working) + plane format + mode name."""
+    """``products`` (1 or 3; this IS the int, so architecture code written against an int keeps working) + plane format + mode name.
+    For 'mixed' the pair is the DEFAULT of layers / buffers the architecture's table does not name."""
 
-    def __new__(cls, name: str):
-        products, fmt = PRECISIONS[name]
+    def __new__(cls, name: str, table: dict | None = None):
+        products, fmt = (table or {}).get(name, PRECISIONS[name])
         obj = super().__new__(cls, products)
         obj.name, obj.fmt = name, fmt
         return obj
@@ -45,6 +46,14 @@ class Prec(int):
 
 class Fp16Range(ValueError):
     """A weight does not fit fp16: the module falls back to 'bf16x3' (with a warning)."""
+
+
+def check_fp16_range(weights) -> None:
+    """Pack-time guard of the fp16 modes: raise ``Fp16Range`` when a convolution weight packed in fp16 exceeds the format's range
+    (one device synchronisation per pack).  ``weights``: an iterable of ``ops.ConvWeights`` (others are skipped)."""
+    amax = [cw.w.abs().amax() for cw in weights if isinstance(cw, ops.ConvWeights) and cw.fmt == PF_F16 and cw.w is not None]
+    if amax and float(torch.stack(amax).amax()) > 6.0e4:
+        raise Fp16Range('a convolution weight exceeds the fp16 range (|w| > 6e4)')
 
 
 def conv_algorithmic_bytes(p: L.ConvParams) -> int:
@@ -69,8 +78,9 @@ def conv_algorithmic_bytes(p: L.ConvParams) -> int:
 class Plan:
     """Buffers + launch list for one (batch, H, W, dtype, device, precision) signature."""
 
-    def __init__(self, device):
+    def __init__(self, device, fmt: int = PF_BF16):
         self.device = device
+        self.fmt = fmt  # plane format of buffers a builder does not give one for (the module's resolved precision)
         self.keep: list[object] = []  # tensors referenced by raw pointer in the descriptors
         self.steps: list[Callable[[], None]] = []  # executed in order on the current stream
         self._pending: list[L.ConvParams] = []
@@ -79,8 +89,8 @@ class Plan:
         self._pending_cin: list = []
 
     # ---- buffers ----
-    def planes(self, n, planes, h, w, with_lo=True, fmt: int = PF_BF16, lo_planes: int | None = None) -> Planes:
-        p = Planes.empty(n, planes, h, w, self.device, with_lo, fmt, lo_planes)
+    def planes(self, n, planes, h, w, with_lo=True, fmt: int | None = None, lo_planes: int | None = None) -> Planes:
+        p = Planes.empty(n, planes, h, w, self.device, with_lo, self.fmt if fmt is None else fmt, lo_planes)
         self.keep.append(p)
         return p
 
@@ -232,6 +242,7 @@ class EngineModule(nn.Module):
     #: what ``precision = 'auto'`` resolves to, and the modes this architecture implements (subclasses widen both)
     auto_precision = 'bf16x3'
     precisions = ('bf16x3', 'bf16')
+    precision_table: dict = {}  # mode name -> (default products, default plane format) where an architecture departs from PRECISIONS
 
     def resolved_precision(self) -> str:
         name = self.precision
@@ -244,7 +255,7 @@ class EngineModule(nn.Module):
     @property
     def products(self) -> Prec:
         """The resolved precision as an int-compatible ``Prec`` (``int(prec)`` = matrix products per layer without a per-layer rule)."""
-        return Prec(self.resolved_precision())
+        return Prec(self.resolved_precision(), self.precision_table)
 
     # -- hooks --
     def _pack(self, device, products: int):
@@ -322,7 +333,7 @@ class EngineModule(nn.Module):
         key = (shape, x.dtype, str(x.device), self.resolved_precision())
         entry = self._plans.pop(key, None)
         if entry is None:
-            plan = Plan(x.device)
+            plan = Plan(x.device, self.products.fmt)
             set_input, get_output = self._build_plan(plan, packed, shape, x.dtype, self.products)
             plan.flush()
             entry = [plan, set_input, get_output, None]

@@ -68,8 +68,12 @@ class ConvWeights:
     fmt: int = PF_BF16  # enum rsa_plane_fmt of the blob = of the input planes this layer multiplies
 
     @staticmethod
-    def from_oihw(w: torch.Tensor, b: torch.Tensor | None, products: int, cin_planes: int | None = None, device=None, fmt: int = PF_BF16) -> 'ConvWeights':
+    def from_oihw(w: torch.Tensor, b: torch.Tensor | None, products: int, cin_planes: int | None = None, device=None, fmt: int | None = None) -> 'ConvWeights':
+        """``products`` may be the module's ``Prec`` (an int that also names the plane format): ``fmt`` then defaults to it."""
         device = device if device is not None else w.device
+        if fmt is None:
+            fmt = getattr(products, 'fmt', PF_BF16)
+        products = int(products)
         cout, cin, k, _ = w.shape
         if cin_planes is None:
             cin_planes = (cin + 7) // 8

@@ -19,8 +19,8 @@ import torch
 
 from . import lib as L
 from . import ops
-from .base import Plan
-from .tensors import Planes
+from .base import Plan, check_fp16_range
+from .tensors import PF_F16, Planes
 
 
 def fold_conv3xc(sd: dict, prefix: str) -> tuple[torch.Tensor, torch.Tensor]:
@@ -65,21 +65,25 @@ def spab_shapes(shapes: dict, name: str, c: int) -> None:
 class SpabChain:
     """Emits the launches of [block_1, block_n..., block_end, conv_2, conv_cat] into a plan."""
 
-    def __init__(self, plan: Plan, W: dict, n: int, h: int, w: int, fc: int, act: int, with_lo: bool):
+    def __init__(self, plan: Plan, W: dict, n: int, h: int, w: int, fc: int, act: int, with_lo: bool, cat_lo: bool | None = None):
         self.plan, self.W, self.n, self.h, self.w, self.fc, self.act = plan, W, n, h, w, fc, act
         self.pf = fc // 8
         self.with_lo = with_lo
+        # 'mixed': the scratch planes between the convolutions of a SPAB are hi only, the cat buffer (input of the three-product conv_cat,
+        # and the gate's shortcut of the first SPAB) keeps hi + lo
+        self.cat_lo = with_lo if cat_lo is None else cat_lo
         # scratch shared by every SPAB of the model
         self.t1 = plan.planes(n, self.pf, h, w, with_lo)
         self.t2 = plan.planes(n, self.pf, h, w, with_lo)
         self.ping = [plan.planes(n, self.pf, h, w, with_lo) for _ in range(2)]
         # The gate's shortcut is read from the block input's own split planes (value = hi + lo, 16 bits) in bf16x3 mode: no f32 copy of
-        # every block output is written and read back (-12 % of a SPAB's bytes).  Plain-bf16 mode has no lo planes and keeps the f32 maps.
-        self.plane_shortcut = with_lo
+        # every block output is written and read back (-12 % of a SPAB's bytes).  Plain-bf16 mode has no lo planes and keeps the f32 maps;
+        # fp16 mode reads the shortcut from the hi plane (11 bits: what an fp16 run of the reference modules carries between layers).
+        self.plane_shortcut = with_lo or plan.fmt == PF_F16
         self.f32 = [None] * 3 if self.plane_shortcut else [plan.f32map(n, fc, h, w) for _ in range(3)]
 
     def new_cat(self) -> Planes:
-        return self.plan.planes(self.n, 4 * self.pf, self.h, self.w, self.with_lo)
+        return self.plan.planes(self.n, 4 * self.pf, self.h, self.w, self.cat_lo)
 
     def _conv(self, name, x, **kw):
         self.plan.conv(ops.conv_params(self.W[name], x, self.h, self.w, cin_planes=self.pf, **kw))
@@ -114,12 +118,31 @@ class SpabChain:
         self.plan.conv(ops.conv_params(self.W[names['conv_cat']], cat, self.h, self.w, cin_planes=4 * pf, out=out, out_plane_off=out_plane0, out_f32=out_f32))
 
 
+#: the SPAN family's 'mixed' table (what their 'auto' selects).  The 19-20 re-parameterised 3x3 convolutions -- 95 % of the multiply-accumulates,
+#: every one followed by the SPAB gate's (sigmoid - 0.5) attenuation or another such block -- run ONE fp16 product on hi planes; the layers
+#: whose output reaches the image at full amplitude (conv_cat over the four concatenated maps, the upsampler head) run three fp16 products on
+#: hi + lo planes, and so does the first convolution (3 input channels: its output is slot 0 of the cat buffer).  CPU emulation on SPANPlus x4
+#: (tests/test_precision_policy.py): 4e-6 max-abs against fp32 where one product everywhere gives 2.1e-4 (conv_cat, the head and the first
+#: convolution contribute 0.7-1.6e-4 each) -- with fp16 output tensors the former is half an ulp of the output, the latter is not.
+SPAN_MIXED = {'mixed': (1, PF_F16)}
+SPAN_FIRST = ('feats.0', 'conv_1')  # the first convolution of SPANPlus / SPAN
+
+
+def span_layer_policy(name: str, conv3xc: bool) -> tuple[int, int]:
+    """(products, plane format) of a SPAN-family layer under 'mixed'."""
+    return (1, PF_F16) if conv3xc and name not in SPAN_FIRST else (3, PF_F16)
+
+
 def pack_span_family(module, device, products: int, conv3xc_names: list[str], plain_names: list[str]) -> dict:
     sd = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in module.state_dict().items()}
+    mixed = getattr(products, 'name', '') == 'mixed'
     W = {}
     for name in conv3xc_names:
         w, b = fold_conv3xc(sd, name)
-        W[name] = ops.ConvWeights.from_oihw(w, b, products, device=device)
+        prod, fmt = span_layer_policy(name, True) if mixed else (int(products), getattr(products, 'fmt', None))
+        W[name] = ops.ConvWeights.from_oihw(w, b, prod, device=device, fmt=fmt)
     for name in plain_names:
-        W[name] = ops.ConvWeights.from_oihw(sd[f'{name}.weight'], sd.get(f'{name}.bias'), products, device=device)
+        prod, fmt = span_layer_policy(name, False) if mixed else (int(products), getattr(products, 'fmt', None))
+        W[name] = ops.ConvWeights.from_oihw(sd[f'{name}.weight'], sd.get(f'{name}.bias'), prod, device=device, fmt=fmt)
+    check_fp16_range(W.values())
     return W

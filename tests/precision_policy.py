@@ -82,3 +82,54 @@ def rrdbnet_auto(key: str) -> str:
     if key.startswith('model.1.sub.'):
         return 'fp16x3'
     return 'bf16x3'
+
+
+class _FProxy:
+    """``torch.nn.functional`` with ``conv2d`` rounded per policy (the plain convolutions of the SPAN oracles: conv_cat, the upsampler)."""
+
+    def __init__(self, policy):
+        self.policy, self.idx = policy, 0
+
+    def __getattr__(self, k):
+        return getattr(F, k)
+
+    def conv2d(self, x, w, b=None, padding=0, **kw):
+        mode = self.policy(f'plain{self.idx}')
+        self.idx += 1
+        if w.shape[-1] == 1 or padding == 1:
+            return round_conv(x, w, b, mode)
+        return F.conv2d(x, w, b, padding=padding, **kw)
+
+
+@contextmanager
+def emulate_span(policy, shortcut_dtype: torch.dtype | None = None):
+    """Patch the SPAN / SPANPlus oracle: every Conv3XC becomes its folded 3x3 convolution rounded as ``policy(prefix)`` says, the plain
+    convolutions (numbered in call order: conv_cat ..., upsampler) as ``policy('plainN')``; the SPAB gate's shortcut is rounded to
+    ``shortcut_dtype`` (the engine reads it from the hi plane in its one-product modes)."""
+    import oracle.span as O
+
+    orig = O.conv3xc, O.F, O.spab
+
+    def c3(sd, prefix, x):
+        w, b = O.conv3xc_fold(sd, prefix)
+        return round_conv(x, w, b, policy(prefix))
+
+    def spab(sd, prefix, x, act):
+        out1 = act(c3(sd, f'{prefix}.c1_r', x))
+        out2 = c3(sd, f'{prefix}.c2_r', out1)
+        out3 = c3(sd, f'{prefix}.c3_r', act(out2))
+        xs = x if shortcut_dtype is None else x.to(shortcut_dtype).float()
+        return (out3 + xs) * (torch.sigmoid(out3) - 0.5), out1
+
+    O.conv3xc, O.spab, O.F = c3, spab, _FProxy(policy)
+    try:
+        yield
+    finally:
+        O.conv3xc, O.F, O.spab = orig
+
+
+def span_mixed(key: str) -> str:
+    """The SPAN family's 'mixed' table (resselt_amd/engine/spanblocks.py::span_layer_policy): Conv3XC layers in one fp16 product; the first
+    convolution and the plain convolutions (conv_cat, the upsampler head) in three fp16 products."""
+    return 'fp16x3' if key.startswith('plain') or key in ('feats.0', 'conv_1') else 'fp16'
+

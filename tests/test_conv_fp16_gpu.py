@@ -197,14 +197,15 @@ def test_failed_hand_off_is_an_error(device):
     p = ops.conv_params(wts, xin, h, w, out=out)
     torch.cuda.synchronize()
     L.check_status('before')
-    before = L.ring_aborts()
+    assert L.ring_aborts() == 0
     L.set_ring_spin_limit(1)
     try:
         ops.run_convs([p], device)
         torch.cuda.synchronize()
     finally:
         L.set_ring_spin_limit(1 << 18)
-    if L.ring_aborts() == before:
+    if L.ring_aborts() == 0:  # (reads and clears the debug counter: later tests start from zero again)
+        L.check_status('nothing timed out')
         pytest.skip('every hand-off was ready at its first poll: nothing timed out on this run')
     with pytest.raises(RuntimeError, match='hand-off'):
         ops.run_convs([p], device)  # refused: a failure is pending

@@ -59,3 +59,25 @@ def test_mixed_policy_on_heavy_tailed_weights():
     e = _errors(sd, x, {'mixed': (P.rrdbnet_auto, torch.float16)})
     print(e)
     assert e['mixed'] <= 2e-4
+
+
+def test_span_mixed_policy_on_spanplus_x4():
+    """SPANPlus x4 (BASELINE config 3's network): which layers spend the error budget.  One fp16 product everywhere: 2.1e-4 (f32 output
+    tensors), 0.7-1.6e-4 of it from each of conv_cat, the upsampler head and the first convolution; with those three in three fp16 products: 4e-6."""
+    import oracle.span as O
+    from resselt_amd.engine.spanblocks import span_layer_policy
+    from resselt_amd.engine.tensors import PF_F16
+
+    assert span_layer_policy('feats.1.block_1.c1_r', True) == (1, PF_F16) and span_layer_policy('feats.1.conv_cat', False) == (3, PF_F16)
+    assert span_layer_policy('feats.0', True) == (3, PF_F16) and span_layer_policy('conv_1', True) == (3, PF_F16)
+    torch.set_num_threads(8)
+    sd = synth.spanplus_state_dict(upscale=4, upsampler='ps', seed=0)
+    x = synth.synth_input((2, 3, 96, 96), seed=0).half().float()
+    with torch.no_grad():
+        ref = O.spanplus_forward(sd, x)
+        with P.emulate_span(P.span_mixed, torch.float16):
+            mixed = (O.spanplus_forward(sd, x) - ref).abs().max().item()
+        with P.emulate_span(P.uniform('fp16'), torch.float16):
+            one = (O.spanplus_forward(sd, x) - ref).abs().max().item()
+    print(mixed, one)
+    assert mixed <= 2e-5 and one > 1e-4

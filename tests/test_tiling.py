@@ -140,8 +140,8 @@ def test_choose_grid_keeps_tile_aspect():
 
 
 def test_bench_power_sampler_matches_samples_by_wall_clock(tmp_path, monkeypatch):
-    """bench.py's power leg: a child process samples `rocm-smi` (stubbed here) and the bench keeps the samples inside its window; without
-    rocm-smi on the PATH the field is null instead of an error."""
+    """bench.py's power leg: a child process samples `rocm-smi -d <this GPU>` (stubbed here) once the bench reaches its power leg -- it stays
+    idle before ``begin()`` -- and the bench keeps the samples inside its window; without rocm-smi on the PATH the field is null instead of an error."""
     import importlib.util
     import stat
     import sys
@@ -151,14 +151,19 @@ def test_bench_power_sampler_matches_samples_by_wall_clock(tmp_path, monkeypatch
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     fake = tmp_path / 'rocm-smi'
-    fake.write_text('#!/bin/sh\necho "GPU[0]\t\t: sclk clock level: 1: (1970Mhz)"\necho "GPU[0]\t\t: Max Graphics Package Power (W): 1400.0"\n'
-                    'echo "GPU[0]\t\t: Current Socket Graphics Package Power (W): 1366.0"\n'
-                    'echo "GPU[1]\t\t: sclk clock level: S: (95Mhz)"\necho "GPU[1]\t\t: Max Graphics Package Power (W): 1400.0"\n'
-                    'echo "GPU[1]\t\t: Current Socket Graphics Package Power (W): 240.0"\n')
+    # (the stub answers for the device the sampler asks for with -d: device 0 here)
+    fake.write_text('#!/bin/sh\n[ "$1" = "-d" ] && [ "$2" = "0" ] || exit 1\n'
+                    'echo "GPU[0]\t\t: sclk clock level: 1: (1970Mhz)"\necho "GPU[0]\t\t: Max Graphics Package Power (W): 1400.0"\n'
+                    'echo "GPU[0]\t\t: Current Socket Graphics Package Power (W): 1366.0"\n')
     fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
     monkeypatch.setenv('PATH', f'{tmp_path}{os.pathsep}{os.environ["PATH"]}')
+    monkeypatch.delenv('HIP_VISIBLE_DEVICES', raising=False)
+    monkeypatch.delenv('ROCR_VISIBLE_DEVICES', raising=False)
     s = bench.PowerSampler()
     assert s.proc is not None
+    time.sleep(0.7)
+    assert os.path.getsize(s.path) == 0  # idle until the power leg begins: nothing sampled during load / warm-up / the timed region
+    s.begin()
     t0 = time.time()
     time.sleep(1.5)
     got = s.stop(t0, time.time())

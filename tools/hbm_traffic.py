@@ -24,12 +24,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def family(name: str) -> str:
     name = name.replace('void ', '')
-    if 'conv_ring<2' in name:
-        return 'rsa::conv_ring<2,UP,0> (Cout<=32)'
-    if 'conv_ring<3' in name:
-        return 'rsa::conv_ring<3,UP,0> (Cout 33..48)'
-    if 'conv_ring<1' in name:
-        return 'rsa::conv_ring<1,UP,0> (Cout 49..64)'
+    if 'conv_ring<' in name:  # conv_ring<SHAPE, UP, OUTK, HM, FMT, PROD>
+        import re
+
+        a = [int(v) for v in re.findall(r'-?\d+', name.split('conv_ring<')[1].split('>')[0])]
+        a += [0] * (6 - len(a))
+        shape, fmt, prod = a[0], a[4], (a[5] or 3)
+        cout = {2: 'Cout<=32', 3: 'Cout 33..48', 1: 'Cout 49..64'}.get(shape, '?')
+        return f'rsa::conv_ring<{shape},...,{"f16" if fmt else "bf16"},{prod}> ({cout}, {prod} product{"s" if prod > 1 else ""})'
     if 'conv_kernel_pp' in name:
         return 'rsa::conv_kernel_pp'
     if 'conv_kernel' in name:

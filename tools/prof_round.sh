@@ -16,8 +16,8 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_f -- python3 $R/bench.py 
 python3 $R/tools/rocpd_export.py pmc $(find /tmp/prof_f -name '*.db' | head -1) /tmp/fetch.csv
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/prof_w -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-roofline --no-power > $R/gpurun_out/${tag}_prof_w.log 2>&1
 python3 $R/tools/rocpd_export.py pmc $(find /tmp/prof_w -name '*.db' | head -1) /tmp/write.csv
-N=$(grep -c "conv_" /tmp/fetch.csv)
-python3 $R/tools/hbm_traffic.py /tmp/fetch.csv /tmp/write.csv $((N / 351)) $R/gpurun_out/${tag}_hbm_traffic.json > /dev/null
+# forwards in a `--steps 1 --warmup 0` bench run: the timed step + one untimed and one timed forward of the kernel-time leg
+python3 $R/tools/hbm_traffic.py /tmp/fetch.csv /tmp/write.csv 3 $R/gpurun_out/${tag}_hbm_traffic.json > /dev/null
 echo traffic done
 cut -c1-330 $R/gpurun_out/${tag}_sq_counters.txt
 head -c 1200 $R/gpurun_out/${tag}_hbm_traffic.json

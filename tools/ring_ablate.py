@@ -2,7 +2,8 @@
 """Runtime ablations of the ring schedule on an experiment build (tools/variant.sh dbg "-DRSA_RING_DEBUG"; RSA_LIB=variants/lib_dbg.so).
 
 mask bits: 1 no DMA, 2 no MFMA, 4 no weight loads, 8 no epilogue, 16 no LDS fragment reads.
-usage: RSA_LIB=variants/lib_dbg.so ring_ablate.py cin,cout [...] -- mask [mask ...]
+usage: RSA_LIB=variants/lib_dbg.so [MODE=fp16] ring_ablate.py cin,cout [...] -- mask [mask ...]
+MODE=fp16: the one-product fp16 layers of the 'mixed' policy (Cout 32: hi-only output; Cout 64: conv5 with both plane residuals, hi + lo output).
 """
 
 import os
@@ -29,14 +30,30 @@ dev = torch.device('cuda:0')
 lib = L.load()
 H, W = 1080, 1920
 reps = 5
+fp16 = os.environ.get('MODE') == 'fp16'
 for cin, cout in configs:
     w = (torch.rand((cout, cin, 3, 3)) - 0.5) * 0.1
-    wts = ops.ConvWeights.from_oihw(w, torch.zeros(cout), 3, device=dev)
-    x = tensors.Planes.empty(1, cin // 8, H, W, dev)
-    x.hi.copy_(torch.randn(x.hi.shape, device=dev).to(torch.bfloat16))
-    x.lo.copy_((torch.randn(x.lo.shape, device=dev) * 0.004).to(torch.bfloat16))
-    out = tensors.Planes.empty(1, (cout + 7) // 8, H, W, dev)
-    p = ops.conv_params(wts, x, H, W, out=out, act=L.ACT_LRELU, act_param=0.2)
+    if fp16:
+        wts = ops.ConvWeights.from_oihw(w, torch.zeros(cout), 1, device=dev, fmt=tensors.PF_F16)
+        x = tensors.Planes.empty(1, cin // 8, H, W, dev, True, tensors.PF_F16, lo_planes=8)
+        x.hi.copy_(torch.randn(x.hi.shape, device=dev).to(torch.float16))
+        x.lo.copy_((torch.randn(x.lo.shape, device=dev) * 0.0004).to(torch.float16))
+        if cout == 64:
+            r2 = tensors.Planes.empty(1, cin // 8, H, W, dev, True, tensors.PF_F16, lo_planes=8)
+            r2.hi.copy_(x.hi)
+            r2.lo.copy_(x.lo)
+            out = tensors.Planes.empty(1, cin // 8, H, W, dev, True, tensors.PF_F16, lo_planes=8)
+            p = ops.conv_params(wts, x, H, W, out=out, res1=(x, 0), alpha=0.2, res2=(r2, 0), beta=0.2)
+        else:
+            out = tensors.Planes.empty(1, (cout + 7) // 8, H, W, dev, False, tensors.PF_F16)
+            p = ops.conv_params(wts, x, H, W, out=out, act=L.ACT_LRELU, act_param=0.2)
+    else:
+        wts = ops.ConvWeights.from_oihw(w, torch.zeros(cout), 3, device=dev)
+        x = tensors.Planes.empty(1, cin // 8, H, W, dev)
+        x.hi.copy_(torch.randn(x.hi.shape, device=dev).to(torch.bfloat16))
+        x.lo.copy_((torch.randn(x.lo.shape, device=dev) * 0.004).to(torch.bfloat16))
+        out = tensors.Planes.empty(1, (cout + 7) // 8, H, W, dev)
+        p = ops.conv_params(wts, x, H, W, out=out, act=L.ACT_LRELU, act_param=0.2)
     arr = (L.ConvParams * 1)(p)
     stream = ops.current_stream_ptr(dev)
     res = {}
@@ -53,4 +70,4 @@ for cin, cout in configs:
             if rnd:
                 res.setdefault(m, []).append(e0.elapsed_time(e1) / reps)
     lib.rsa_debug_ring_flags(0)
-    print(f'{cin}->{cout}: ' + '  '.join(f'[{m}] {statistics.median(t):.3f}' for m, t in res.items()) + f'  aborts={L.ring_aborts()}', flush=True)
+    print(f'{L.conv_kernel_name(p)} {cin}->{cout}: ' + '  '.join(f'[{m}] {statistics.median(t):.3f}' for m, t in res.items()) + f'  aborts={L.ring_aborts()}', flush=True)
