@@ -61,6 +61,8 @@ def parse():
     ap.add_argument('--no-power', action='store_true', help='skip the socket-power leg (rocm-smi sampled by a child process started before the GPU is touched)')
     ap.add_argument('--no-kernel-roofline', action='store_true', help='skip the per-kernel replays (profiling runs: keeps the launch mix that of plain forwards)')
     ap.add_argument('--dry-run', action='store_true', help='launcher / rendezvous check without a GPU: ranks meet over gloo, rank 0 prints a stub line')
+    ap.add_argument('--io', default='f32', choices=['f32', 'u8'], help='tensors crossing the boundary: fp32 [N,C,H,W] in / out, or uint8 [N,H,W,C] images in / out '
+                    '(the 8-bit path: /255 and clamp*255+round inside the first / last kernel; tiles cross xGMI as bytes)')
     ap.add_argument('--config', default='c2', choices=['c2', 'c5'], help='c2: N tiles of 1080p (weak scaling); c5: one 4320x7680 input, 2x4 tiles (strong scaling)')
     return ap.parse_args()
 
@@ -349,17 +351,24 @@ def main():
         rows, cols = 2, 4
         img_h, img_w = 4 * H, 4 * W
         assert (img_h, img_w) == (rows * 2 * H, cols * W)
-        inner = lambda crop: upscale_tiled(model, crop, 4, tile=(H + 2 * args.halo, W + 2 * args.halo), halo=args.halo)  # noqa: E731
+        if args.io == 'u8':
+            from resselt_amd.tiling import upscale
+
+            inner = lambda crop: upscale(model, crop, tile=(H + 2 * args.halo, W + 2 * args.halo), halo=args.halo, scale=4)  # noqa: E731
+        else:
+            inner = lambda crop: upscale_tiled(model, crop, 4, tile=(H + 2 * args.halo, W + 2 * args.halo), halo=args.halo)  # noqa: E731
         runner = TileParallel(inner, scale=4, halo=args.halo, grid=(rows, cols))
     else:
-        # N tiles of HxW (weak scaling): 1x2, 2x2, 2x4 for N = 2, 4, 8 -- the grid that keeps the 16:9 tile aspect
-        rows, cols = choose_grid(world, H, W) if world > 1 else (1, 1)
+        # N tiles of HxW (weak scaling) stacked as N x 1 full-width row bands: an interior band reads 2 x halo extra rows (5.9 % of a 1080p
+        # tile; a 2 x 4 grid of the same tiles reads halos on three sides, 9.5 %), its 1144 x 1920 window is 72 x 60 = 4320 ring tiles =
+        # 16.9 per CU, and the bands of an 8-bit image are contiguous slabs of the result, so the all-gather lands in place
+        rows, cols = (world, 1)
         img_h, img_w = rows * H, cols * W
-        if world == 8:
-            assert (rows, cols) == (2, 4) and (img_h, img_w) == (2 * H, 4 * W)
         runner = TileParallel(model, scale=4, halo=args.halo, grid=(rows, cols)) if world > 1 else model
     # the same full input image on every rank (3 channels: cheap to replicate); each rank owns its tile(s) of it
     x = synth.synth_input((1, 3, img_h, img_w), seed=0).to(dev)
+    if args.io == 'u8':
+        x = (x * 255).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()  # [1, H, W, 3] image
 
     def step():
         return runner(x)  # N > 1: tile forward + RCCL all-gather; every rank ends with the whole upscaled image
@@ -398,7 +407,7 @@ def main():
     if aborts != 0:
         raise SystemExit(f'bench.py: {aborts} ring-schedule hand-offs timed out; the timed forwards are invalid')
 
-    total_out_px = y.shape[-1] * y.shape[-2] * y.shape[0]  # whole image (on every rank after the all-gather)
+    total_out_px = (y.shape[1] * y.shape[2] if args.io == 'u8' else y.shape[-1] * y.shape[-2]) * y.shape[0]  # whole image (on every rank after the all-gather)
     assert total_out_px == 16 * img_h * img_w
     ms_per_step = dt / args.steps * 1e3
     value = total_out_px / 1e6 / (dt / args.steps)
@@ -408,7 +417,7 @@ def main():
         # kernel-only time of the conv launches of one forward of ONE HxW frame, from HIP events on the launch stream
         k0 = torch.cuda.Event(enable_timing=True)
         k1 = torch.cuda.Event(enable_timing=True)
-        xt = x[:, :, :H, :W].contiguous()
+        xt = (x[:, :H, :W] if args.io == 'u8' else x[:, :, :H, :W]).contiguous()
         model(xt)
         torch.cuda.synchronize()
         k0.record()
@@ -446,9 +455,10 @@ def main():
         dom_mfma, dom_hbm = dom['tflops'] / MFMA_PEAK_TFLOPS, dom.get('gbs', 0.0) / HBM_PEAK_GBS
         dom_bound = 'hbm' if dom_hbm > dom_mfma else 'mfma'
         tile_note = {
-            'c2': f'{rows}x{cols} tiles of {H}x{W} (+{args.halo} px input halo), one per GPU, RCCL all-gather of fp32 output tiles' if world > 1 else 'single tile',
+            'c2': (f'{rows}x{cols} full-width row bands of {H}x{W} (+{args.halo} rows of input halo), one per GPU; one asynchronous RCCL all-gather of '
+                   + ('uint8 HWC output bands straight into the result image' if args.io == 'u8' else 'fp32 output tiles')) if world > 1 else 'single tile',
             'c5': f'one 3x{img_h}x{img_w} input, 2x4 tiles of {2 * H}x{W} (+{args.halo} px halo) dealt round-robin to {world} rank(s), each run as 1080p-sized sub-tiles; '
-            + ('RCCL all-gather of fp32 output tiles' if world > 1 else 'no collective'),
+            + ((f'one asynchronous RCCL all-gather of {"uint8" if args.io == "u8" else "fp32"} output tiles per round of {world} tiles, beside the next round\'s compute') if world > 1 else 'no collective'),
         }[args.config]
         res = {
             'metric': 'output megapixels/sec, RealESRGAN-x4plus 1080p\u21924K, 1/2/4/8 MI355X',
@@ -464,11 +474,12 @@ def main():
             'dtype': 'fp16' if prec == 'mixed' else 'bf16',  # the arithmetic type of the dominant layers (config.precision names the whole policy)
             'data': 'synthetic',
             'config': {
-                'workload': (f'RealESRGAN-x4plus (RRDBNet nf64 nb{args.blocks} gc32 x4), 1x3x{H}x{W} fp32 frame per GPU -> 1x3x{4 * H}x{4 * W}, ' if args.config == 'c2' else
-                             f'RealESRGAN-x4plus (RRDBNet nf64 nb{args.blocks} gc32 x4), ONE 1x3x{img_h}x{img_w} fp32 image -> 1x3x{4 * img_h}x{4 * img_w} over all GPUs (BASELINE configs[4]), ')
+                'workload': (f'RealESRGAN-x4plus (RRDBNet nf64 nb{args.blocks} gc32 x4), 1x3x{H}x{W} {"uint8" if args.io == "u8" else "fp32"} frame per GPU -> 1x3x{4 * H}x{4 * W}, ' if args.config == 'c2' else
+                             f'RealESRGAN-x4plus (RRDBNet nf64 nb{args.blocks} gc32 x4), ONE 1x3x{img_h}x{img_w} {"uint8" if args.io == "u8" else "fp32"} image -> 1x3x{4 * img_h}x{4 * img_w} over all GPUs (BASELINE configs[4]), ')
                 + prec_note + ', synthetic uniform(+-1/sqrt(fan_in)) weights',
                 'precision': args.precision if args.precision == prec else f'{args.precision} -> {prec}',
                 'precision_policy': prec_note,
+                'io': 'uint8 [N,H,W,C] images in and out' if args.io == 'u8' else 'fp32 [N,C,H,W] tensors in and out',
                 'tile_parallel': tile_note,
                 'launches_per_step': n_launch,
             },

@@ -256,6 +256,8 @@ typedef struct rsa_layernorm_params {
   int64_t out_plane_stride; /* 16-byte units */
   int64_t out_batch_stride;
   float* out_f32;          /* optional f32 NCHW4c copy of the result */
+  int32_t out_fmt;         /* enum rsa_plane_fmt of out_hi / out_lo */
+  int32_t reserved0;       /* must be 0 */
 } rsa_layernorm_params;
 
 int rsa_layernorm(const rsa_layernorm_params* p, void* stream);
@@ -382,6 +384,9 @@ typedef struct rsa_swin_block_params {
   void* out_lo;
   int64_t out_plane_stride; /* 16-byte units */
   int64_t out_batch_stride;
+  int32_t fmt;             /* enum rsa_plane_fmt of the packed weights, of the on-chip operand images and of out_hi / out_lo.  fp16 is compiled
+                              for products == 1: that instantiation keeps no lo images, its LDS array is 64 KB and two windows share a CU */
+  int32_t reserved0;       /* must be 0 */
 } rsa_swin_block_params;
 
 int rsa_swin_block(const rsa_swin_block_params* p, void* stream);

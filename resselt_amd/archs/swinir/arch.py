@@ -20,7 +20,7 @@ import torch
 
 from ...engine import lib as L
 from ...engine import ops, swinblocks
-from ...engine.base import EngineModule, Plan
+from ...engine.base import EngineModule, Plan, check_fp16_range
 from ...engine.paramtree import build_param_tree
 
 RGB_MEAN = (0.4488, 0.4371, 0.4040)  # resselt/archs/swinir/arch.py:788-790
@@ -198,6 +198,18 @@ class SwinIR(EngineModule):
     # layer-by-layer path (LayerNorm, Linear layers as k1 convolutions, rsa_window_attention).  The fused kernels take C <= 256,
     # <= 8 heads of <= 32 channels, window <= 8, hidden <= 512; other widths run layer by layer whatever this says.
     fused_blocks = 'whole'
+    # 'fp16' (what 'auto' selects when every block runs as one fused launch): ONE fp16 product per multiply -- weights, LayerNorm outputs,
+    # q / k / v, softmax probabilities and hidden activations rounded to 11 bits, f32 accumulation, the residual stream in f32 throughout.
+    # The one-product block kernel keeps no lo images: 64 KB of LDS, two windows per CU.  Pinned at <= 2e-4 on fp32 tensors by
+    # tests/test_baseline_configs_gpu.py (C4, full depth).  Models the fused kernels do not take keep 'bf16x3' under 'auto'.
+    precisions = ('bf16x3', 'bf16', 'fp16')
+
+    @property
+    def auto_precision(self) -> str:
+        hidden = int(self.embed_dim * self.mlp_ratio)
+        fused = self.fused_blocks == 'whole' and swinblocks.mlp_block_fits(self.embed_dim, hidden)
+        fused = fused and all(h <= 8 and self.embed_dim // h <= HEAD_PAD for h in self.num_heads)
+        return 'fp16' if fused else 'bf16x3'
 
     def __init__(self, *, img_size=64, patch_size=1, in_chans=3, embed_dim=96, depths=(6, 6, 6, 6), num_heads=(6, 6, 6, 6), window_size=7,
                  mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1, ape=False,
@@ -273,6 +285,7 @@ class SwinIR(EngineModule):
                 conv(name)
         mean = torch.tensor(RGB_MEAN if self.in_chans == 3 else [0.0] * self.in_chans, dtype=torch.float32, device=device)
         W['mean'] = mean
+        check_fp16_range(W.values())
         return W
 
     def macs_per_input_pixel(self) -> int:
@@ -341,6 +354,9 @@ class SwinIR(EngineModule):
         def can_fuse(heads):
             return self.fused_blocks and swinblocks.mlp_block_fits(C_, hidden) and heads <= 8 and C_ // heads <= HEAD_PAD
 
+        if products.name == 'fp16' and not (self.fused_blocks == 'whole' and all(can_fuse(h) for h in self.num_heads)):
+            raise NotImplementedError("SwinIR 'fp16' needs every block on the whole-block kernel (fused_blocks = 'whole', C <= 256, <= 8 heads of <= 32 "
+                                      "channels, hidden <= 512); use precision 'bf16x3' or 'bf16'")  # fmt: skip
         if all(can_fuse(h) for h in self.num_heads):
             qkv_pl = o_pl = hid_pl = None  # nothing between the residual stream and itself leaves the chip
         else:
@@ -360,6 +376,7 @@ class SwinIR(EngineModule):
                 lp.out_hi, lp.out_lo = out_planes.hi_ptr(), out_planes.lo_ptr()
                 lp.out_plane_stride, lp.out_batch_stride = out_planes.plane_stride, out_planes.batch_stride
             lp.out_f32 = None if out_f32 is None else out_f32.data_ptr()
+            lp.out_fmt = plan.fmt
             plan.call(lambda: L.check(lib.rsa_layernorm(C.byref(lp), C.c_void_p(ops.current_stream_ptr(dev))), 'rsa_layernorm'))
             plan.count_launches(1)
 
@@ -401,6 +418,7 @@ class SwinIR(EngineModule):
             bp.wproj, bp.bproj = proj.packed_for(0).data_ptr(), proj.bias.data_ptr()
             bp.w1, bp.b1, bp.w2, bp.b2 = fc1.packed_for(0).data_ptr(), fc1.bias.data_ptr(), fc2.packed_for(0).data_ptr(), fc2.bias.data_ptr()
             bp.out = out_f32.data_ptr()
+            bp.fmt = plan.fmt
             if out_planes is not None:
                 bp.out_hi, bp.out_lo = out_planes.hi_ptr(), out_planes.lo_ptr()
                 bp.out_plane_stride, bp.out_batch_stride = out_planes.plane_stride, out_planes.batch_stride

@@ -124,16 +124,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const rsa_layernorm_para
         if (pl * 2 + 1 < p4) ((f32x4*)p.out_f32)[((int64_t)n * p4 + pl * 2 + 1) * HW + pix] = (f32x4){y[4], y[5], y[6], y[7]};
       }
       if (p.out_hi != nullptr) {
-        bf16x8 h, l;
+        typedef __attribute__((ext_vector_type(8))) uint16_t u16x8;
+        u16x8 h, l;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const __bf16 hb = (__bf16)y[j];
-          h[j] = hb;
-          l[j] = (__bf16)(y[j] - (float)hb);
+          if (p.out_fmt == RSA_PF_F16) {
+            const _Float16 hb = (_Float16)y[j];
+            h[j] = __builtin_bit_cast(uint16_t, hb);
+            l[j] = __builtin_bit_cast(uint16_t, (_Float16)(y[j] - (float)hb));
+          } else {
+            const __bf16 hb = (__bf16)y[j];
+            h[j] = __builtin_bit_cast(uint16_t, hb);
+            l[j] = __builtin_bit_cast(uint16_t, (__bf16)(y[j] - (float)hb));
+          }
         }
         const int64_t unit = (int64_t)n * p.out_batch_stride + (int64_t)pl * p.out_plane_stride + pix;
-        ((bf16x8*)p.out_hi)[unit] = h;
-        if (p.out_lo != nullptr) ((bf16x8*)p.out_lo)[unit] = l;
+        ((u16x8*)p.out_hi)[unit] = h;
+        if (p.out_lo != nullptr) ((u16x8*)p.out_lo)[unit] = l;
       }
     };
     if (live) {
@@ -379,6 +386,7 @@ extern "C" int rsa_layernorm(const rsa_layernorm_params* p, void* stream) {
   if (p == nullptr) return set_error(RSA_E_ARG, "layernorm: null params");
   if (p->batch < 1 || p->H < 1 || p->W < 1 || p->C < 1) return set_error(RSA_E_ARG, "layernorm: bad geometry");
   if (!p->x_f32 || !p->gamma || !p->beta || (!p->out_hi && !p->out_f32)) return set_error(RSA_E_ARG, "layernorm: null pointer");
+  if ((p->out_fmt != RSA_PF_BF16 && p->out_fmt != RSA_PF_F16) || p->reserved0 != 0) return set_error(RSA_E_ARG, "layernorm: out_fmt must be an rsa_plane_fmt");
   if (((uintptr_t)p->x_f32 | (uintptr_t)p->out_hi | (uintptr_t)p->out_lo | (uintptr_t)p->out_f32) & 15)
     return set_error(RSA_E_ALIGN, "layernorm: maps must be 16-byte aligned");
   const int64_t total = (int64_t)p->batch * p->H * p->W;

@@ -40,7 +40,7 @@ __device__ __forceinline__ void ln_load(LnRow& r, const f32x4* x_img, int64_t HW
 
 // statistics by lane shuffles (the 8 lanes of a token sit 8 apart), result as split planes; planes [ceil(C/8), planes_pad) and
 // tokens without a pixel (pix < 0) get zeros
-template <int PROD>
+template <int PROD, int FMT = 0>
 __device__ __forceinline__ void ln_store(const LnRow& r, uint4* lds, int lo0, int planes_pad, int C, const float* gamma, const float* beta, float eps,
                                          int t, int64_t pix, int lane) {
   const int j = lane >> 3;
@@ -87,8 +87,8 @@ __device__ __forceinline__ void ln_store(const LnRow& r, uint4* lds, int lo0, in
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = (r.v[i][hh][e] - mean) * rstd * ga[e] + be[e];
       }
-      split2(y[0], y[1], h[2 * hh], l[2 * hh]);
-      split2(y[2], y[3], h[2 * hh + 1], l[2 * hh + 1]);
+      split2<FMT>(y[0], y[1], h[2 * hh], l[2 * hh]);
+      split2<FMT>(y[2], y[3], h[2 * hh + 1], l[2 * hh + 1]);
     }
     lds[pl * SB_TOK + t] = make_uint4(h[0], h[1], h[2], h[3]);
     if (PROD == 3) lds[lo0 + pl * SB_TOK + t] = make_uint4(l[0], l[1], l[2], l[3]);
@@ -116,7 +116,7 @@ __device__ __forceinline__ void w0_load(W0<PROD, CTW>& f, const __amdgpu_buffer_
 // this lane's fragment of cout tile c inside a chunk, or 0xFFFFFFFF (a tile beyond the layer: the range check of the buffer load
 // looks at the vector offset alone and returns zeros).  SWAP: tokens on the MFMA rows (D[token][channel]) instead of the columns.
 // XDB false: the token fragments are single-buffered (32 registers less; their LDS latency is then exposed once per chunk).
-template <int PROD, int CTW, int NPT, bool SWAP, bool XDB = true>
+template <int PROD, int CTW, int NPT, bool SWAP, bool XDB = true, int FMT = 0>
 __device__ __forceinline__ void gemm_tile(f32x4 (&acc)[CTW][NPT], const uint4* lds, int lo0, int nk, const __amdgpu_buffer_rsrc_t rw,
                                           const uint32_t (&woff)[CTW], uint32_t wstep, const W0<PROD, CTW>& w0, int li, int lg) {
   constexpr int NHL = PROD == 3 ? 2 : 1;
@@ -157,13 +157,10 @@ __device__ __forceinline__ void gemm_tile(f32x4 (&acc)[CTW][NPT], const uint4* l
       for (int c = 0; c < CTW; ++c) {
         // products in increasing magnitude: w_lo*x_hi, w_hi*x_lo, w_hi*x_hi
         if (PROD == 3) {
-          acc[c][pt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[xb][pt], w[b][c][NHL - 1], acc[c][pt], 0, 0, 0)
-                            : __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[b][c][NHL - 1], bh[xb][pt], acc[c][pt], 0, 0, 0);
-          acc[c][pt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[xb][pt], w[b][c][0], acc[c][pt], 0, 0, 0)
-                            : __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[b][c][0], bl[xb][pt], acc[c][pt], 0, 0, 0);
+          acc[c][pt] = SWAP ? mfma16<FMT>(bh[xb][pt], w[b][c][NHL - 1], acc[c][pt]) : mfma16<FMT>(w[b][c][NHL - 1], bh[xb][pt], acc[c][pt]);
+          acc[c][pt] = SWAP ? mfma16<FMT>(bl[xb][pt], w[b][c][0], acc[c][pt]) : mfma16<FMT>(w[b][c][0], bl[xb][pt], acc[c][pt]);
         }
-        acc[c][pt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[xb][pt], w[b][c][0], acc[c][pt], 0, 0, 0)
-                          : __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[b][c][0], bh[xb][pt], acc[c][pt], 0, 0, 0);
+        acc[c][pt] = SWAP ? mfma16<FMT>(bh[xb][pt], w[b][c][0], acc[c][pt]) : mfma16<FMT>(w[b][c][0], bh[xb][pt], acc[c][pt]);
       }
   };
   if (RSA_SB_ABL & 8) {
@@ -207,24 +204,25 @@ __device__ __forceinline__ void gemm_tile(f32x4 (&acc)[CTW][NPT], const uint4* l
   if (kc < nk) multiply(0);
 }
 
-// eight f32 values -> the bf16 hi fragment and (PROD 3) the residual fragment
+// eight f32 values -> the hi fragment (plane format FMT) and (PROD 3) the residual fragment
+template <int FMT = 0>
 __device__ __forceinline__ void frag_of(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
   uint32_t h[4], l[4];
-  split2(a[0], a[1], h[0], l[0]);
-  split2(a[2], a[3], h[1], l[1]);
-  split2(b[0], b[1], h[2], l[2]);
-  split2(b[2], b[3], h[3], l[3]);
+  split2<FMT>(a[0], a[1], h[0], l[0]);
+  split2<FMT>(a[2], a[3], h[1], l[1]);
+  split2<FMT>(b[0], b[1], h[2], l[2]);
+  split2<FMT>(b[2], b[3], h[3], l[3]);
   hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
   lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
 }
 
-template <int PROD>
+template <int PROD, int FMT = 0>
 __device__ __forceinline__ f32x4 mfma3(const bf16x8 ah, const bf16x8 al, const bf16x8 bh, const bf16x8 bl, f32x4 c) {
   if (PROD == 3) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+    c = mfma16<FMT>(al, bh, c);
+    c = mfma16<FMT>(ah, bl, c);
   }
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+  return mfma16<FMT>(ah, bh, c);
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const void* w, int64_t bytes) {

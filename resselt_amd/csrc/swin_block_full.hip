@@ -12,8 +12,10 @@
 
 namespace rsa {
 
-template <int PROD>
-__global__ __launch_bounds__(512) void swin_block_kernel(const rsa_swin_block_params p) {
+// PROD 1 (one product, bf16 or fp16 per FMT): no lo images, so the array is 64 KB and TWO windows share a CU -- one window's LayerNorm /
+// softmax / GELU / barrier phases then sit beside the other's multiplies (launch bounds: 4 waves per SIMD = 128 registers).
+template <int PROD, int FMT>
+__global__ __launch_bounds__(512, PROD == 1 ? 4 : 2) void swin_block_kernel(const rsa_swin_block_params p) {
   constexpr int HPL = 64;  // planes of the LDS image (512 hidden channels); the token / attention-output images use planes 0..31
   constexpr int LO0 = HPL * SB_TOK;
   // While the token / attention-output images are in use (hi planes 0..31, lo planes 64..95) the other half of the array is free:
@@ -21,10 +23,12 @@ __global__ __launch_bounds__(512) void swin_block_kernel(const rsa_swin_block_pa
   // planes 96..123) and come back as proj's shortcut -- the residual stream is fetched from memory exactly once per block (15 us
   // after norm1 read them the lines have left the L2: measured 1 GB of re-fetch per launch).  Widths above 240 channels have no
   // room for that and read the shortcut from memory.  norm2's partial sums: lo planes 124..127.
+  // One product: only groups 0..31 are parked (hi planes 32..63), the rest of the shortcut is read from memory again; norm2's partial sums
+  // reuse the first planes of the parked rows (they are consumed before proj starts).
   constexpr int STASH0 = 32 * SB_TOK, STASH1 = 96 * SB_TOK;
-  constexpr int RED0 = 124 * SB_TOK;
+  constexpr int RED0 = (PROD == 3 ? 124 : 32) * SB_TOK;
   constexpr int NHL = PROD == 3 ? 2 : 1;
-  __shared__ uint4 s_h[2 * HPL * SB_TOK];  // 128 KB
+  __shared__ uint4 s_h[(PROD == 3 ? 2 : 1) * HPL * SB_TOK];  // 128 KB / 64 KB
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -70,22 +74,20 @@ __global__ __launch_bounds__(512) void swin_block_kernel(const rsa_swin_block_pa
   for (int c = 0; c < 2; ++c) woff_2[c] = (2 * wave + c < ct_c) ? (uint32_t)(((2 * wave + c) * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
   W0<PROD, 4> w0qk;
   w0_load<PROD, 4>(w0qk, rq, woff_qk);
-  const bool stash = p4 <= 60;
+  const int stash_groups = PROD == 3 ? (p4 <= 60 ? p4 : 0) : min(p4, 32);  // channel groups of the shortcut parked in LDS
   {
     const int t = wave * 8 + (lane & 7);
     const int64_t pix = token_pix(t);
     LnRow row;
     ln_load(row, x_img, HW, p4, pix, lane);
-    if (stash) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int g = ((lane >> 3) + 8 * i) * 2 + h;
-          if (g < p4) s_h[(g < 32 ? STASH0 + g * SB_TOK : STASH1 + (g - 32) * SB_TOK) + t] = __builtin_bit_cast(uint4, row.v[i][h]);
-        }
-    }
-    ln_store<PROD>(row, s_h, LO0, 4 * nk, p.C, p.gamma1, p.beta1, p.eps, t, pix, lane);
+      for (int h = 0; h < 2; ++h) {
+        const int g = ((lane >> 3) + 8 * i) * 2 + h;
+        if (g < stash_groups) s_h[(g < 32 ? STASH0 + g * SB_TOK : STASH1 + (g - 32) * SB_TOK) + t] = __builtin_bit_cast(uint4, row.v[i][h]);
+      }
+    ln_store<PROD, FMT>(row, s_h, LO0, 4 * nk, p.C, p.gamma1, p.beta1, p.eps, t, pix, lane);
   }
   __syncthreads();
 
@@ -118,21 +120,47 @@ __global__ __launch_bounds__(512) void swin_block_kernel(const rsa_swin_block_pa
     for (int c = 0; c < 2; ++c) woff_v[c] = (uint32_t)((((2 * heads + head) * 2 + c) * NHL * 64 + lane) * 16);
     bf16x8 qh[4], ql[4], kh[4], kl[4];
     W0<PROD, 2> w0v;
-    {
+    if constexpr (PROD == 3) {
       f32x4 a[4][4];
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) a[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      gemm_tile<PROD, 4, 4, false, true>(a, s_h, LO0, nk, rq, woff_qk, qstep, w0qk, li, lg);
+      gemm_tile<PROD, 4, 4, false, true, FMT>(a, s_h, LO0, nk, rq, woff_qk, qstep, w0qk, li, lg);
       w0_load<PROD, 2>(w0v, rq, woff_v);
       f32x4 b[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) b[c] = bqkv4[(((c >> 1) * heads + head) * 2 + (c & 1)) * 4 + lg];
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
-        frag_of(a[0][tt] + b[0], a[1][tt] + b[1], qh[tt], ql[tt]);
-        frag_of(a[2][tt] + b[2], a[3][tt] + b[3], kh[tt], kl[tt]);
+        frag_of<FMT>(a[0][tt] + b[0], a[1][tt] + b[1], qh[tt], ql[tt]);
+        frag_of<FMT>(a[2][tt] + b[2], a[3][tt] + b[3], kh[tt], kl[tt]);
+      }
+    } else {
+      // one product, 128 registers (two windows per CU): q and k in two passes of two cout tiles, each with half the accumulators
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        f32x4 a[2][4];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int pt = 0; pt < 4; ++pt) a[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const uint32_t wo[2] = {woff_qk[2 * half], woff_qk[2 * half + 1]};
+        W0<PROD, 2> w0h;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) w0h.w[c][0] = w0qk.w[2 * half + c][0];
+        gemm_tile<PROD, 2, 4, false, true, FMT>(a, s_h, LO0, nk, rq, wo, qstep, w0h, li, lg);
+        if (half == 1) w0_load<PROD, 2>(w0v, rq, woff_v);
+        f32x4 b[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) b[c] = bqkv4[((half * heads + head) * 2 + c) * 4 + lg];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          if (half == 0)
+            frag_of<FMT>(a[0][tt] + b[0], a[1][tt] + b[1], qh[tt], ql[tt]);
+          else
+            frag_of<FMT>(a[0][tt] + b[0], a[1][tt] + b[1], kh[tt], kl[tt]);
+        }
       }
     }
     bf16x8 vh[2][2], vl[2][2];
@@ -142,15 +170,16 @@ __global__ __launch_bounds__(512) void swin_block_kernel(const rsa_swin_block_pa
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) a[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      gemm_tile<PROD, 2, 4, true, true>(a, s_h, LO0, nk, rq, woff_v, qstep, w0v, li, lg);
+      // (one product: q and k fragments are live beside this multiply; its token fragments are single-buffered to stay within 128 registers)
+      gemm_tile<PROD, 2, 4, true, PROD == 3, FMT>(a, s_h, LO0, nk, rq, woff_v, qstep, w0v, li, lg);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         const float bv = p.bqkv[((2 * heads + head) * 2 + dt) * 16 + li];
 #pragma unroll
-        for (int kp = 0; kp < 2; ++kp) frag_of(a[dt][2 * kp] + bv, a[dt][2 * kp + 1] + bv, vh[dt][kp], vl[dt][kp]);
+        for (int kp = 0; kp < 2; ++kp) frag_of<FMT>(a[dt][2 * kp] + bv, a[dt][2 * kp + 1] + bv, vh[dt][kp], vl[dt][kp]);
       }
     }
-    f32x4 o[2][4];
+    f32x4 o[2][2];  // [channel tile][query tile of the current pair]: packed into plane units every second query tile
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
       f32x4 s[4];
@@ -158,7 +187,7 @@ __global__ __launch_bounds__(512) void swin_block_kernel(const rsa_swin_block_pa
       float m = -3.0e38f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
-        s[kt] = mfma3<PROD>(kh[kt], kl[kt], qh[qt], ql[qt], (f32x4){0.f, 0.f, 0.f, 0.f});
+        s[kt] = mfma3<PROD, FMT>(kh[kt], kl[kt], qh[qt], ql[qt], (f32x4){0.f, 0.f, 0.f, 0.f});
         const f32x4 bf = ((const f32x4*)p.bias_frag16)[(((int64_t)head * 4 + kt) * 4 + qt) * 64 + lane];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -184,19 +213,19 @@ __global__ __launch_bounds__(512) void swin_block_kernel(const rsa_swin_block_pa
       const float inv_l = 1.f / l;
       bf16x8 ph[2], pl[2];
 #pragma unroll
-      for (int kp = 0; kp < 2; ++kp) frag_of(s[2 * kp], s[2 * kp + 1], ph[kp], pl[kp]);
+      for (int kp = 0; kp < 2; ++kp) frag_of<FMT>(s[2 * kp], s[2 * kp + 1], ph[kp], pl[kp]);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kp = 0; kp < 2; ++kp) acc = mfma3<PROD>(vh[dt][kp], vl[dt][kp], ph[kp], pl[kp], acc);
-        o[dt][qt] = acc * inv_l;
+        for (int kp = 0; kp < 2; ++kp) acc = mfma3<PROD, FMT>(vh[dt][kp], vl[dt][kp], ph[kp], pl[kp], acc);
+        o[dt][qt & 1] = acc * inv_l;
+      }
+      if (qt & 1) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) pair_units<FMT>(o[dt][0], o[dt][1], ouh[dt * 2 + (qt >> 1)], oul[dt * 2 + (qt >> 1)]);
       }
     }
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int k = 0; k < 2; ++k) pair_units(o[dt][2 * k], o[dt][2 * k + 1], ouh[dt * 2 + k], oul[dt * 2 + k]);
   }
   w0_load<PROD, 2>(w0p, rp, woff_2);
   __syncthreads();  // every wave has read the norm1 image for the last time
@@ -220,8 +249,8 @@ __global__ __launch_bounds__(512) void swin_block_kernel(const rsa_swin_block_pa
       const int g = (2 * wave + c) * 4 + lg;
       const int t = 16 * pt + li;
       x1[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (stash) {
-        if (t < ntok && g < p4) x1[c][pt] = __builtin_bit_cast(f32x4, s_h[(g < 32 ? STASH0 + g * SB_TOK : STASH1 + (g - 32) * SB_TOK) + t]);
+      if (g < stash_groups) {
+        if (t < ntok) x1[c][pt] = __builtin_bit_cast(f32x4, s_h[(g < 32 ? STASH0 + g * SB_TOK : STASH1 + (g - 32) * SB_TOK) + t]);
       } else {
         const int64_t px = token_pix(t);
         if (px >= 0 && g < p4) x1[c][pt] = x_img[(int64_t)g * HW + px];
@@ -230,9 +259,12 @@ __global__ __launch_bounds__(512) void swin_block_kernel(const rsa_swin_block_pa
   __syncthreads();
 
   // ---- proj + bias + shortcut -> x1 (registers) ----
+  // hidden cout tiles of this wave: two in the lower half of the hidden image (tiles 2w, 2w+1: planes below 32, where the norm2 image lives
+  // while fc1 reads it) and two in the upper half (16 + 2w, 16 + 2w + 1: free planes, stored as soon as they are computed)
+  auto hid_tile = [&](int c) -> int { return (c < 2 ? 0 : 16) + 2 * wave + (c & 1); };
   uint32_t woff_1[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) woff_1[c] = (4 * wave + c < ct_h) ? (uint32_t)(((4 * wave + c) * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
+  for (int c = 0; c < 4; ++c) woff_1[c] = (hid_tile(c) < ct_h) ? (uint32_t)((hid_tile(c) * NHL * 64 + lane) * 16) : 0xFFFFFFFFu;
   W0<PROD, 4> w01;
   {
     f32x4 a[2][4];
@@ -240,7 +272,7 @@ __global__ __launch_bounds__(512) void swin_block_kernel(const rsa_swin_block_pa
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int pt = 0; pt < 4; ++pt) a[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    gemm_tile<PROD, 2, 4, false, true>(a, s_h, LO0, heads, rp, woff_2, (uint32_t)ct_c * NHL * 1024u, w0p, li, lg);
+    gemm_tile<PROD, 2, 4, false, true, FMT>(a, s_h, LO0, heads, rp, woff_2, (uint32_t)ct_c * NHL * 1024u, w0p, li, lg);
     w0_load<PROD, 4>(w01, r1, woff_1);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -315,7 +347,7 @@ __global__ __launch_bounds__(512) void swin_block_kernel(const rsa_swin_block_pa
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         uint4 uh, ul;
-        pair_units(y[2 * k], y[2 * k + 1], uh, ul);
+        pair_units<FMT>(y[2 * k], y[2 * k + 1], uh, ul);
         const int u = (2 * ct + (lg >> 1)) * SB_TOK + 16 * (2 * k + (lg & 1)) + li;
         s_h[u] = uh;
         if (PROD == 3) s_h[LO0 + u] = ul;
@@ -324,9 +356,9 @@ __global__ __launch_bounds__(512) void swin_block_kernel(const rsa_swin_block_pa
   }
   __syncthreads();
 
-  // ---- fc1 + GELU: wave owns hidden cout tiles 4*wave .. +3, in two passes of two tiles (x1 stays in registers beside them: four
-  //      tiles at once do not fit); the results wait as plane units until every wave is done with the norm2 image ----
-  uint4 hu[4][2], hl[4][2];  // [cout tile][token tile pair]
+  // ---- fc1 + GELU in two passes of two cout tiles (x1 stays in registers beside them: four tiles at once do not fit).  The lower-half
+  //      tiles wait as plane units until every wave is done with the norm2 image; the upper-half tiles go straight into their planes ----
+  uint4 hu[2][2], hl[2][2];  // [lower-half cout tile][token tile pair]
   W0<PROD, 2> w02;
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
@@ -341,11 +373,11 @@ __global__ __launch_bounds__(512) void swin_block_kernel(const rsa_swin_block_pa
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int hl_ = 0; hl_ < NHL; ++hl_) w0h.w[c][hl_] = w01.w[2 * ps + c][hl_];
-    gemm_tile<PROD, 2, 4, false, true>(a1, s_h, LO0, nk, r1, wo, (uint32_t)ct_h * NHL * 1024u, w0h, li, lg);
+    gemm_tile<PROD, 2, 4, false, PROD == 3, FMT>(a1, s_h, LO0, nk, r1, wo, (uint32_t)ct_h * NHL * 1024u, w0h, li, lg);
     if (ps == 1) w0_load<PROD, 2>(w02, r2, woff_2);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const int ct = 4 * wave + 2 * ps + c;
+      const int ct = hid_tile(2 * ps + c);
       f32x4 b = {0.f, 0.f, 0.f, 0.f};
       if (ct < ct_h) b = ((const f32x4*)p.b1)[ct * 4 + lg];
 #pragma unroll
@@ -353,13 +385,25 @@ __global__ __launch_bounds__(512) void swin_block_kernel(const rsa_swin_block_pa
 #pragma unroll
         for (int r = 0; r < 4; ++r) a1[c][pt][r] = gelu_fast(a1[c][pt][r] + b[r]);  // tiles beyond the layer: GELU(0) = 0
 #pragma unroll
-      for (int k = 0; k < 2; ++k) pair_units(a1[c][2 * k], a1[c][2 * k + 1], hu[2 * ps + c][k], hl[2 * ps + c][k]);
+      for (int k = 0; k < 2; ++k) {
+        if (ps == 0) {
+          pair_units<FMT>(a1[c][2 * k], a1[c][2 * k + 1], hu[c][k], hl[c][k]);
+        } else {
+          uint4 uh, ul;
+          pair_units<FMT>(a1[c][2 * k], a1[c][2 * k + 1], uh, ul);
+          if (ct < 2 * nk2) {  // planes 32 and up: nobody reads them before the barrier below (the K padding gets its zeros too)
+            const int u = (2 * ct + (lg >> 1)) * SB_TOK + 16 * (2 * k + (lg & 1)) + li;
+            s_h[u] = uh;
+            if (PROD == 3) s_h[LO0 + u] = ul;
+          }
+        }
+      }
     }
   }
   __syncthreads();  // every wave has read the norm2 image (and the partial sums) for the last time
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int ct = 4 * wave + c;
+  for (int c = 0; c < 2; ++c) {
+    const int ct = 2 * wave + c;
     if (ct >= 2 * nk2) continue;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -377,7 +421,7 @@ __global__ __launch_bounds__(512) void swin_block_kernel(const rsa_swin_block_pa
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int pt = 0; pt < 4; ++pt) a[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    gemm_tile<PROD, 2, 4, false, true>(a, s_h, LO0, nk2, r2, woff_2, (uint32_t)ct_c * NHL * 1024u, w02, li, lg);
+    gemm_tile<PROD, 2, 4, false, true, FMT>(a, s_h, LO0, nk2, r2, woff_2, (uint32_t)ct_c * NHL * 1024u, w02, li, lg);
     f32x4* o_img = (f32x4*)p.out + (int64_t)n * p4 * HW;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -399,7 +443,7 @@ __global__ __launch_bounds__(512) void swin_block_kernel(const rsa_swin_block_pa
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           uint4 uh, ul;
-          pair_units(a[c][2 * k], a[c][2 * k + 1], uh, ul);
+          pair_units<FMT>(a[c][2 * k], a[c][2 * k + 1], uh, ul);
           const int pl = 2 * ct + (lg >> 1);
           const int64_t pix = token_pix(16 * (2 * k + (lg & 1)) + li);
           if (pix >= 0 && pl < planes) {
@@ -435,10 +479,14 @@ extern "C" int rsa_swin_block(const rsa_swin_block_params* p, void* stream) {
   if (!aligned16f(p->out_hi) || !aligned16f(p->out_lo)) return set_error(RSA_E_ALIGN, "swin_block: pointers must be 16-byte aligned");
   const int64_t windows = (int64_t)p->batch * (p->H / p->window) * (p->W / p->window);
   if (windows > 0x3fffffff) return set_error(RSA_E_UNSUPPORTED, "swin_block: too many windows");
+  if ((p->fmt != RSA_PF_BF16 && p->fmt != RSA_PF_F16) || p->reserved0 != 0) return set_error(RSA_E_ARG, "swin_block: fmt must be an rsa_plane_fmt");
+  if (p->fmt == RSA_PF_F16 && p->products != 1) return set_error(RSA_E_UNSUPPORTED, "swin_block: fp16 operands are compiled for products == 1");
   if (p->products == 3)
-    hipLaunchKernelGGL(swin_block_kernel<3>, dim3((unsigned)windows), dim3(512), 0, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL((swin_block_kernel<3, RSA_PF_BF16>), dim3((unsigned)windows), dim3(512), 0, (hipStream_t)stream, *p);
+  else if (p->fmt == RSA_PF_F16)
+    hipLaunchKernelGGL((swin_block_kernel<1, RSA_PF_F16>), dim3((unsigned)windows), dim3(512), 0, (hipStream_t)stream, *p);
   else
-    hipLaunchKernelGGL(swin_block_kernel<1>, dim3((unsigned)windows), dim3(512), 0, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL((swin_block_kernel<1, RSA_PF_BF16>), dim3((unsigned)windows), dim3(512), 0, (hipStream_t)stream, *p);
   const int rc = (int)hipGetLastError();
   return rc ? set_error(rc, "swin_block: launch failed") : RSA_OK;
 }

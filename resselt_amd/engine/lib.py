@@ -115,6 +115,8 @@ class LayerNormParams(C.Structure):
         ('out_plane_stride', C.c_int64),
         ('out_batch_stride', C.c_int64),
         ('out_f32', C.c_void_p),
+        ('out_fmt', C.c_int32),
+        ('reserved0', C.c_int32),
     ]
 
 
@@ -202,6 +204,8 @@ class SwinBlockParams(C.Structure):
         ('out_lo', C.c_void_p),
         ('out_plane_stride', C.c_int64),
         ('out_batch_stride', C.c_int64),
+        ('fmt', C.c_int32),
+        ('reserved0', C.c_int32),
     ]
 
 
@@ -435,6 +439,10 @@ EXPORTS = (
 
 
 def lib_path() -> str:
+    """The in-tree library; RSA_LIB=path selects an experiment build instead (tools/variant.sh: A/B timing, ablations)."""
+    override = os.environ.get('RSA_LIB')
+    if override:
+        return os.path.abspath(override)
     return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), _LIB_NAME)
 
 

@@ -79,15 +79,21 @@ def plan_tiles(height: int, width: int, rows: int, cols: int, halo: int = 32, al
     return tiles
 
 
+def _is_image(x: torch.Tensor) -> bool:
+    """uint8 [N, H, W, C] images (what a decoder delivers; models with ``supports_u8`` read and write them) vs float [N, C, H, W] tensors."""
+    return x.dtype == torch.uint8
+
+
 def run_tile(model: Callable[[torch.Tensor], torch.Tensor], x: torch.Tensor, tile: Tile, scale: int) -> torch.Tensor:
-    """Upscale one tile (with its halo) and crop the halo off the result."""
+    """Upscale one tile (with its halo) and crop the halo off the result (a view of the model's output, not a copy)."""
+    img = _is_image(x)
     if tile.y1 <= tile.y0 or tile.x1 <= tile.x0:
         return x.new_zeros((x.shape[0], 0, 0, 0))
-    crop = x[:, :, tile.ry0 : tile.ry1, tile.rx0 : tile.rx1].contiguous()
+    crop = (x[:, tile.ry0 : tile.ry1, tile.rx0 : tile.rx1] if img else x[:, :, tile.ry0 : tile.ry1, tile.rx0 : tile.rx1]).contiguous()
     y = model(crop)
     oy, ox = (tile.y0 - tile.ry0) * scale, (tile.x0 - tile.rx0) * scale
     th, tw = tile.shape
-    return y[:, :, oy : oy + th * scale, ox : ox + tw * scale]
+    return y[:, oy : oy + th * scale, ox : ox + tw * scale] if img else y[:, :, oy : oy + th * scale, ox : ox + tw * scale]
 
 
 def upscale_tiled(model, x: torch.Tensor, scale: int, tile: tuple[int, int], halo: int = 32, align: int = 1) -> torch.Tensor:
@@ -158,13 +164,23 @@ class TileParallel:
     all ranks return the complete upscaled image.
 
     ``x`` must be the same full input on every rank (a 3-channel image is cheap to replicate; only the outputs and
-    the activations are large).  With ``world_size`` ranks the image is cut into ``world_size`` tiles (one per rank)
-    unless ``grid`` says otherwise; tiles are assigned round-robin.
+    the activations are large): a float ``[N, C, H, W]`` tensor, or -- for models with ``supports_u8`` -- a uint8
+    ``[N, H, W, C]`` image, in which case the tiles that cross the links are 8-bit (a quarter of the fp32 bytes).
+    With ``world_size`` ranks the image is cut into ``world_size`` tiles (one per rank) unless ``grid`` says otherwise;
+    tiles are dealt round-robin: rank r owns tiles r, r + world, ...
+
+    The collective: one ``all_gather_into_tensor`` per ROUND of tiles (round k = tiles k*world .. k*world + world - 1),
+    issued asynchronously as soon as this rank's tile of the round is finished, so it runs (on the backend's own stream)
+    beside the computation of the next round's tile; all of them are waited for once, at the end.  When the tiles of a
+    round are equal full-width row bands of a channel-interleaved image (uint8 ``[1, H, W, C]``: the bands of a round are
+    one contiguous slab of the result) the gather writes straight into the result; otherwise tiles are padded to the
+    largest tile, gathered into a receive buffer and copied into place.
     """
 
     def __init__(self, model: Callable[[torch.Tensor], torch.Tensor], scale: int, halo: int = 32, align: int = 1,
-                 grid: tuple[int, int] | None = None, group=None):  # fmt: skip
-        self.model, self.scale, self.halo, self.align, self.grid, self.group = model, scale, halo, align, grid, group
+                 grid: tuple[int, int] | None = None, group=None, overlap: bool = True):  # fmt: skip
+        self.model, self.scale, self.halo, self.align, self.grid, self.group, self.overlap = model, scale, halo, align, grid, group, overlap
+        self.last_stats: dict = {}
 
     def tiles_for(self, height: int, width: int, world: int) -> list[Tile]:
         rows, cols = self.grid if self.grid is not None else choose_grid(world, height, width)
@@ -177,44 +193,86 @@ class TileParallel:
             world, rank = 1, 0
         else:
             world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
-        n, _, h, w = x.shape
+        img = _is_image(x)
+        n = x.shape[0]
+        h, w = (x.shape[1], x.shape[2]) if img else (x.shape[2], x.shape[3])
         s = self.scale
         tiles = self.tiles_for(h, w, world)
         mine = tiles[rank::world]
-        outs = [run_tile(self.model, x, t, s) for t in mine]
-        ref = next((o for o in outs if o.numel()), None)
-        if world == 1:
-            full = torch.empty((n, ref.shape[1], h * s, w * s), dtype=ref.dtype, device=ref.device)
-            for t, o in zip(mine, outs):
+
+        def full_shape(c_out):
+            return (n, h * s, w * s, c_out) if img else (n, c_out, h * s, w * s)
+
+        def place(full, t, o):
+            if img:
+                full[:, t.y0 * s : t.y1 * s, t.x0 * s : t.x1 * s] = o
+            else:
                 full[:, :, t.y0 * s : t.y1 * s, t.x0 * s : t.x1 * s] = o
+
+        if world == 1:
+            full = None
+            for t in mine:
+                o = run_tile(self.model, x, t, s)
+                if full is None:
+                    full = torch.empty(full_shape(o.shape[3] if img else o.shape[1]), dtype=o.dtype, device=o.device)
+                place(full, t, o)
             return full
-        # equal-sized slots so that ONE all-gather moves everything: pad each tile to the largest tile
+
+        rounds = -(-len(tiles) // world)
+        # Can the gather of a round land in the result itself?  Channel-interleaved single image, every tile a full-width row band,
+        # every round complete and made of equal bands.
+        in_place = img and n == 1 and len(tiles) == rounds * world and all(t.x0 == 0 and t.x1 == w for t in tiles) and all(
+            len({t.shape[0] for t in tiles[k * world : (k + 1) * world]}) == 1 for k in range(rounds))  # fmt: skip
         mh = max(t.shape[0] for t in tiles) * s
         mw = max(t.shape[1] for t in tiles) * s
-        per_rank = -(-len(tiles) // world)
-        c_out, dtype, device = self._out_meta(ref, x, idle_ranks=len(tiles) < world)
-        send = torch.zeros((per_rank, n, c_out, mh, mw), dtype=dtype, device=device)
-        for k, (t, o) in enumerate(zip(mine, outs)):
-            if o.numel():
-                send[k, :, :, : o.shape[2], : o.shape[3]] = o
-        recv = torch.empty((world * per_rank, n, c_out, mh, mw), dtype=dtype, device=device)
-        dist.all_gather_into_tensor(recv, send, group=self.group)  # output = concatenation of the ranks' slots along dim 0
-        recv = recv.view(world, per_rank, n, c_out, mh, mw)
-        full = torch.empty((n, c_out, h * s, w * s), dtype=dtype, device=device)
-        for t in tiles:
-            r, k = t.index % world, t.index // world
-            th, tw = t.shape
-            full[:, :, t.y0 * s : t.y1 * s, t.x0 * s : t.x1 * s] = recv[r, k, :, :, : th * s, : tw * s]
+        full = recv = None
+        works, keep = [], []
+        c_out = dtype = device = None
+        for k in range(rounds):
+            t = mine[k] if k < len(mine) else None
+            o = run_tile(self.model, x, t, s) if t is not None else None
+            if c_out is None:
+                ref = o if (o is not None and o.numel()) else None
+                c_out, dtype, device = self._out_meta(ref, x, img, idle_ranks=len(tiles) < world)
+                full = torch.empty(full_shape(c_out), dtype=dtype, device=device)
+                if not in_place:
+                    recv = torch.empty((rounds, world, n, mh, mw, c_out) if img else (rounds, world, n, c_out, mh, mw), dtype=dtype, device=device)
+            if in_place:
+                band = tiles[k * world]
+                dst = full[0, band.y0 * s : tiles[k * world + world - 1].y1 * s].reshape(-1)  # the round's bands: one contiguous slab
+                src = o.reshape(-1) if o.is_contiguous() else o.contiguous().reshape(-1)
+                out_t, in_t = dst, src
+            else:
+                send = torch.zeros((n, mh, mw, c_out) if img else (n, c_out, mh, mw), dtype=dtype, device=device)
+                if o is not None and o.numel():
+                    if img:
+                        send[:, : o.shape[1], : o.shape[2]] = o
+                    else:
+                        send[:, :, : o.shape[2], : o.shape[3]] = o
+                out_t, in_t = recv[k].reshape(-1), send.reshape(-1)
+            keep.append(in_t)  # the input of an asynchronous collective must stay untouched (and alive) until it is waited for
+            work = dist.all_gather_into_tensor(out_t, in_t, group=self.group, async_op=self.overlap)
+            if self.overlap:
+                works.append(work)
+        for wk in works:
+            wk.wait()
+        if not in_place:
+            for t in tiles:
+                k, r = t.index // world, t.index % world
+                th, tw = t.shape
+                place(full, t, recv[k, r, :, : th * s, : tw * s] if img else recv[k, r, :, :, : th * s, : tw * s])
+        self.last_stats = dict(rounds=rounds, in_place=bool(in_place), bytes_per_round=int(keep[0].numel() * keep[0].element_size()) * world,
+                               tile_dtype=str(dtype), overlap=bool(self.overlap))  # fmt: skip
         return full
 
-    def _out_meta(self, ref, x, idle_ranks: bool):
+    def _out_meta(self, ref, x, img: bool, idle_ranks: bool):
         """(channels, dtype, device) of the output tiles.  Only when there are fewer tiles than ranks can a rank have no
         output of its own; ``idle_ranks`` is the same on every rank, so all of them enter the exchange together."""
         import torch.distributed as dist
 
         if not idle_ranks:
-            return ref.shape[1], ref.dtype, ref.device
-        mine = None if ref is None else (ref.shape[1], ref.dtype)
+            return (ref.shape[3] if img else ref.shape[1]), ref.dtype, ref.device
+        mine = None if ref is None else ((ref.shape[3] if img else ref.shape[1]), ref.dtype)
         metas = [None] * dist.get_world_size(self.group)
         dist.all_gather_object(metas, mine, group=self.group)
         c_out, dtype = next(m for m in metas if m is not None)

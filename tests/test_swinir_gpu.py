@@ -109,17 +109,22 @@ def test_window_attention_kernel(device, products, tol, window, shift, heads, hd
         assert got[:, :, hd:].abs().max().item() == 0.0  # padded channels stay exact zeros
 
 
+@pytest.mark.parametrize('precision', ['auto', 'bf16x3'])
 @pytest.mark.parametrize('name', golden_names('swinir_'))
-def test_swinir_matches_reference_vectors(device, name):
+def test_swinir_matches_reference_vectors(device, name, precision):
     meta, arr = load_golden(name)
     sd = synth_state_dict(meta)
     m = resselt_amd.load_from_state_dict(dict(sd)).to(device)
+    assert m.resolved_precision() == 'fp16'  # every fixture runs on the whole-block kernel: 'auto' is one fp16 product
+    m.precision = precision
     assert vars(m.parameters_info) == {k: meta['metadata'][k] for k in ('in_channels', 'out_channels', 'upscale', 'name')}
     y = m(arr['x'].to(device))
     torch.cuda.synchronize()
     assert y.shape == arr['y'].shape
     err = (y.cpu() - arr['y']).abs().max().item()
-    assert err <= 3e-4 * max(1.0, arr['y'].abs().max().item()), f'{name}: max-abs {err:.3e}'
+    print(f'{name} {precision}: max-abs {err:.3e} (|y|max {arr["y"].abs().max():.3f})')
+    assert err <= 3e-4 * max(1.0, arr['y'].abs().max().item()), f'{name} {precision}: max-abs {err:.3e}'
+
 
 
 def test_swinir_L_vs_oracle_bf16_input(device):
@@ -129,11 +134,13 @@ def test_swinir_L_vs_oracle_bf16_input(device):
     with torch.no_grad():
         ref = oracle_forward(dict(arch='swinir'), sd, x)
     m = resselt_amd.load_from_state_dict(dict(sd)).to(device)
-    y = m(x.to(device))
-    assert y.shape == ref.shape == (1, 3, 200, 280)
-    err = (y.cpu() - ref).abs().max().item()
-    print(f'SwinIR-L(3x6) bf16x3 max-abs {err:.3e} (|y|max {ref.abs().max():.2f})')
-    assert err <= 3e-4 * max(1.0, ref.abs().max().item())
+    for precision in ('bf16x3', 'auto'):
+        m.precision = precision
+        y = m(x.to(device))
+        assert y.shape == ref.shape == (1, 3, 200, 280)
+        err = (y.cpu() - ref).abs().max().item()
+        print(f'SwinIR-L(3x6) {precision} ({m.resolved_precision()}) max-abs {err:.3e} (|y|max {ref.abs().max():.2f})')
+        assert err <= 3e-4 * max(1.0, ref.abs().max().item())
     yb = m(x.to(device).bfloat16())
     assert yb.dtype == torch.bfloat16
     with torch.no_grad():
@@ -155,6 +162,7 @@ def test_swinir_block_paths_agree(device, window, embed, heads):
     with torch.no_grad():
         ref = oracle_forward(dict(arch='swinir'), sd, x)
     m = resselt_amd.load_from_state_dict(dict(sd)).to(device)
+    m.precision = 'bf16x3'  # the three paths exist in the three-product mode ('auto' is one fp16 product, on the whole-block kernel only)
     outs = {}
     for mode in ('whole', 'halves', False):
         m.fused_blocks = mode

@@ -54,6 +54,74 @@ def test_single_process_tiling_matches_full_frame():
     assert torch.equal(TileParallel(model, 2, halo=24, grid=(2, 2))(x), upscale_tiled(model, x, scale=2, tile=(23, 31), halo=24))
 
 
+def _u8_model():
+    """uint8 [N, H, W, C] in, uint8 [N, H*2, W*2, C] out (what an engine model with supports_u8 does), on the oracle."""
+    run = _model()
+
+    def f(img):
+        y = run(img.permute(0, 3, 1, 2).float() / 255)
+        return (y.clamp(0, 1) * 255).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+
+    return f
+
+
+def _u8_input():
+    g = torch.Generator().manual_seed(11)
+    return torch.randint(0, 256, (1, 48, 40, 3), generator=g, dtype=torch.uint8)
+
+
+def _u8_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        model, img = _u8_model(), _u8_input()
+        out = {}
+        for name, kw in (('strips', dict(grid=(world, 1))), ('strips2', dict(grid=(2 * world, 1))), ('grid', dict(grid=(world, 2))),
+                         ('ragged', dict(grid=(3, 1))), ('sync', dict(grid=(world, 1), overlap=False))):  # fmt: skip
+            tp = TileParallel(model, scale=2, halo=24, **kw)
+            y = tp(img)
+            out[name] = (y.numpy(), dict(tp.last_stats))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_tile_parallel_u8_images_async_and_in_place(world):
+    """8-bit images through the tile-parallel driver over gloo: one asynchronous all-gather per round of tiles; equal full-width row bands
+    land in the result itself (no receive buffer, no copy); every rank ends with an image bit-identical to the single-process tiling."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_u8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    model, img = _u8_model(), _u8_input()
+    for name, grid in (('strips', (world, 1)), ('strips2', (2 * world, 1)), ('grid', (world, 2)), ('ragged', (3, 1)), ('sync', (world, 1))):
+        single = TileParallel(model, scale=2, halo=24, grid=grid)(img)  # no process group here: the world-size-1 path, same tile plan
+        assert single.dtype == torch.uint8 and tuple(single.shape) == (1, 96, 80, 3)
+        for rank in range(world):
+            y, stats = results[rank][name]
+            assert torch.equal(torch.from_numpy(y), single), (name, rank)
+            assert stats['tile_dtype'] == 'torch.uint8'
+            assert stats['in_place'] == (name in ('strips', 'strips2', 'sync')), (name, stats)
+            assert stats['rounds'] == {'strips': 1, 'strips2': 2, 'grid': 2, 'ragged': -(-3 // world), 'sync': 1}[name]
+            assert stats['overlap'] == (name != 'sync')
+    # uint8 tiles are a quarter of the bytes of the same image as float32 tensors
+    assert results[0]['strips'][1]['bytes_per_round'] == 96 * 80 * 3
+
+
 def _worker(rank, world, port, q):
     import torch.distributed as dist
 

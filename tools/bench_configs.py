@@ -63,13 +63,17 @@ def main():
         if args.only and args.only not in name:
             continue
         model = resselt_amd.load_from_state_dict(dict(sd)).to(dev)
-        for prec in ('bf16x3', 'bf16'):
+        resolved = None
+        for prec in ('auto', 'bf16x3'):
             model.precision = prec
+            if prec != 'auto' and model.resolved_precision() == resolved:
+                continue  # 'auto' already is this mode
+            resolved = model.resolved_precision()
             x = synth.synth_input(shape, seed=0).to(dev).to(dt)
             y, t = timed(model, x, args.reps)
             out_px = y.shape[0] * y.shape[2] * y.shape[3]
             macs = (model.macs_per_input_pixel() if hasattr(model, 'macs_per_input_pixel') else 0) * shape[0] * shape[2] * shape[3]
-            rec = dict(config=name, precision=prec, in_shape=list(shape), io_dtype=str(dt).split('.')[-1], ms=round(t * 1e3, 3),
+            rec = dict(config=name, precision=prec if prec == resolved else f'{prec} -> {resolved}', in_shape=list(shape), io_dtype=str(dt).split('.')[-1], ms=round(t * 1e3, 3),
                        out_mp_s=round(out_px / 1e6 / t, 2), algorithmic_tflops=round(2 * macs / t / 1e12, 2),
                        launches=model.launches_per_forward(), finite=bool(torch.isfinite(y.float()).all()))  # fmt: skip
             if bytes_px:
