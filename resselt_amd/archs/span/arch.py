@@ -14,7 +14,10 @@ from ...engine.spanblocks import SPAN_MIXED, SpabChain, conv3xc_shapes, pack_spa
 class SPAN(EngineModule):
     # 'mixed' (what 'auto' selects; engine/spanblocks.py::SPAN_MIXED): the re-parameterised 3x3 convolutions in ONE fp16 product on hi planes,
     # conv_cat and the upsampler head in three fp16 products on hi + lo planes.  'fp16' = one product everywhere (2e-4: a benchmark mode).
-    auto_precision = 'mixed'
+    # SPAN multiplies its input by 255 (img_range): with activations that large the SPAB gates saturate at +-0.5 and no longer attenuate
+    # what the one-product layers round off (measured 3.3e-4 * max|y| under 'mixed' on the x4 fixture, 1e-5 under 'bf16x3'), so 'auto' keeps
+    # the three-product mode here; 'mixed' / 'fp16' remain available for callers that accept that error.
+    auto_precision = 'bf16x3'
     precisions = ('bf16x3', 'bf16', 'fp16', 'mixed')
     precision_table = SPAN_MIXED
     hyperparameters = {}

@@ -22,6 +22,7 @@ from ...engine import lib as L
 from ...engine import ops, swinblocks
 from ...engine.base import EngineModule, Plan, check_fp16_range
 from ...engine.paramtree import build_param_tree
+from ...engine.tensors import PF_BF16, PF_F16
 
 RGB_MEAN = (0.4488, 0.4371, 0.4040)  # resselt/archs/swinir/arch.py:788-790
 HEAD_PAD = 32  # channels each head occupies in the attention planes
@@ -198,18 +199,34 @@ class SwinIR(EngineModule):
     # layer-by-layer path (LayerNorm, Linear layers as k1 convolutions, rsa_window_attention).  The fused kernels take C <= 256,
     # <= 8 heads of <= 32 channels, window <= 8, hidden <= 512; other widths run layer by layer whatever this says.
     fused_blocks = 'whole'
-    # 'fp16' (what 'auto' selects when every block runs as one fused launch): ONE fp16 product per multiply -- weights, LayerNorm outputs,
-    # q / k / v, softmax probabilities and hidden activations rounded to 11 bits, f32 accumulation, the residual stream in f32 throughout.
-    # The one-product block kernel keeps no lo images: 64 KB of LDS, two windows per CU.  Pinned at <= 2e-4 on fp32 tensors by
-    # tests/test_baseline_configs_gpu.py (C4, full depth).  Models the fused kernels do not take keep 'bf16x3' under 'auto'.
-    precisions = ('bf16x3', 'bf16', 'fp16')
+    # 'mixed' (what 'auto' selects when every block runs as one fused launch): the transformer blocks and the convolution that closes each
+    # residual group -- 95 % of the multiply-accumulates, all of them feeding the f32 residual stream through a LayerNorm -- run ONE fp16
+    # product per multiply (weights, LayerNorm outputs, q / k / v, softmax probabilities, hidden activations rounded to 11 bits, f32
+    # accumulation); the one-product block kernel keeps no lo images: 64 KB of LDS, two windows per CU.  The layers whose output reaches the
+    # image at full amplitude run three products: conv_first and the reconstruction head in bf16 (the kernels of RRDBNet's tail),
+    # conv_after_body in fp16 on the hi + lo output of the last LayerNorm.  One product everywhere ('fp16') measures 6-8e-4 on the
+    # single-convolution heads (pixelshuffledirect, denoising); 'mixed' is pinned at <= 2e-4 on fp32 tensors by
+    # tests/test_baseline_configs_gpu.py (C4, full depth) and test_swinir_gpu.py.  Models the fused kernels do not take keep 'bf16x3'.
+    precisions = ('bf16x3', 'bf16', 'fp16', 'mixed')
+    precision_table = {'mixed': (1, PF_F16)}
 
     @property
     def auto_precision(self) -> str:
         hidden = int(self.embed_dim * self.mlp_ratio)
         fused = self.fused_blocks == 'whole' and swinblocks.mlp_block_fits(self.embed_dim, hidden)
         fused = fused and all(h <= 8 and self.embed_dim // h <= HEAD_PAD for h in self.num_heads)
-        return 'fp16' if fused else 'bf16x3'
+        return 'mixed' if fused else 'bf16x3'
+
+    @staticmethod
+    def layer_policy(name: str) -> tuple[int, int]:
+        """(products, plane format of inputs and weights) of convolution ``name`` under 'mixed'."""
+        if name == 'conv_first':
+            return 3, PF_BF16
+        if name.startswith('conv_after_body'):
+            return 3, PF_F16
+        if name.startswith('layers.'):
+            return 1, PF_F16
+        return 3, PF_BF16  # the reconstruction head
 
     def __init__(self, *, img_size=64, patch_size=1, in_chans=3, embed_dim=96, depths=(6, 6, 6, 6), num_heads=(6, 6, 6, 6), window_size=7,
                  mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1, ape=False,
@@ -243,8 +260,11 @@ class SwinIR(EngineModule):
         sd = {k: v.detach().to(device) for k, v in self.state_dict().items()}
         W: dict = {}
 
+        mixed = products.name == 'mixed'
+
         def conv(name):
-            W[name] = ops.ConvWeights.from_oihw(sd[f'{name}.weight'], sd.get(f'{name}.bias'), products, device=device)
+            prod, fmt = self.layer_policy(name) if mixed else (int(products), products.fmt)
+            W[name] = ops.ConvWeights.from_oihw(sd[f'{name}.weight'], sd.get(f'{name}.bias'), prod, device=device, fmt=fmt)
 
         def lin(name, w=None, b=None, cin_planes=None):
             w = sd[f'{name}.weight'] if w is None else w
@@ -332,11 +352,14 @@ class SwinIR(EngineModule):
         C_, s = self.embed_dim, self.upscale
         hidden = int(C_ * self.mlp_ratio)
         with_lo = products == 3
+        mixed = products.name == 'mixed'
+        wide = with_lo or mixed  # buffers read by a three-product layer under 'mixed' keep hi + lo
+        head_fmt = PF_BF16 if mixed else plan.fmt  # conv_first and the reconstruction head: bf16 planes under 'mixed'
         cp = (C_ + 7) // 8
         dev = plan.device
         lib = L.load()
 
-        x_pl = plan.planes(n, (c + 7) // 8, H, Wd, with_lo)
+        x_pl = plan.planes(n, (c + 7) // 8, H, Wd, wide, head_fmt)
         mean = W['mean']
 
         holder = {}
@@ -348,14 +371,14 @@ class SwinIR(EngineModule):
 
         first = plan.f32map(n, C_, H, Wd)
         pool = [plan.f32map(n, C_, H, Wd) for _ in range(4)]
-        a_pl = plan.planes(n, cp, H, Wd, with_lo)  # LayerNorm output / conv input
+        a_pl = plan.planes(n, cp, H, Wd, wide)  # LayerNorm output / conv input
         max_heads = max(self.num_heads)
 
         def can_fuse(heads):
             return self.fused_blocks and swinblocks.mlp_block_fits(C_, hidden) and heads <= 8 and C_ // heads <= HEAD_PAD
 
-        if products.name == 'fp16' and not (self.fused_blocks == 'whole' and all(can_fuse(h) for h in self.num_heads)):
-            raise NotImplementedError("SwinIR 'fp16' needs every block on the whole-block kernel (fused_blocks = 'whole', C <= 256, <= 8 heads of <= 32 "
+        if products.name in ('fp16', 'mixed') and not (self.fused_blocks == 'whole' and all(can_fuse(h) for h in self.num_heads)):
+            raise NotImplementedError("SwinIR 'fp16' / 'mixed' need every block on the whole-block kernel (fused_blocks = 'whole', C <= 256, <= 8 heads of <= 32 "
                                       "channels, hidden <= 512); use precision 'bf16x3' or 'bf16'")  # fmt: skip
         if all(can_fuse(h) for h in self.num_heads):
             qkv_pl = o_pl = hid_pl = None  # nothing between the residual stream and itself leaves the chip
@@ -363,9 +386,10 @@ class SwinIR(EngineModule):
             qkv_pl = plan.planes(n, 3 * max_heads * HEAD_PAD // 8, H, Wd, with_lo)
             o_pl = plan.planes(n, max_heads * HEAD_PAD // 8, H, Wd, with_lo)
             hid_pl = plan.planes(n, (hidden + 7) // 8, H, Wd, with_lo)
-        body_pl = plan.planes(n, cp, H, Wd, with_lo)
-        q4_a = plan.planes(n, (C_ // 4 + 7) // 8, H, Wd, with_lo) if self.resi == '3conv' else None
-        q4_b = plan.planes(n, (C_ // 4 + 7) // 8, H, Wd, with_lo) if self.resi == '3conv' else None
+        body_pl = plan.planes(n, cp, H, Wd, with_lo)  # the last block of a residual group -> that group's convolution
+        head_pl = plan.planes(n, cp, H, Wd, wide, head_fmt) if mixed else body_pl  # conv_after_body -> the reconstruction head
+        q4_a = plan.planes(n, (C_ // 4 + 7) // 8, H, Wd, wide) if self.resi == '3conv' else None
+        q4_b = plan.planes(n, (C_ // 4 + 7) // 8, H, Wd, wide) if self.resi == '3conv' else None
 
         def layernorm(name, x_f32, out_planes=None, out_f32=None):
             g, b = W[name]
@@ -484,7 +508,10 @@ class SwinIR(EngineModule):
                 free.append(cur)
             cur = out
         layernorm('norm', cur, out_planes=a_pl)
-        resi_conv('conv_after_body', a_pl, first, out_planes=body_pl)  # + conv_first output (arch.py:988)
+        resi_conv('conv_after_body', a_pl, first, out_planes=head_pl)  # + conv_first output (arch.py:988)
+        body_pl = head_pl  # (the head reads conv_after_body's output from here on)
+        with_lo, plan_fmt = wide, plan.fmt
+        plan.fmt = head_fmt  # buffers of the head
 
         out_shape = (n, self.out_chans, H * s, Wd * s)
         out_buf = {'y': torch.empty(out_shape, dtype=dtype, device=dev)}
@@ -526,6 +553,7 @@ class SwinIR(EngineModule):
             base0 = torch.empty((n, self.in_chans, h0, w0), dtype=dtype, device=dev)  # placeholder pointer, patched per call
             plan.conv(ops.conv_params(W['conv_last'], body_pl, H, Wd, cin_planes=cp, out_nchw=out_buf['y'], out_scale=1.0 / self.img_range,
                                       out_base=base0, out_base_div=1))  # fmt: skip
+        plan.fmt = plan_fmt
         arr = plan.flush()
         last_entry = arr[len(arr) - 1]
 

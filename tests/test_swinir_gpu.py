@@ -115,7 +115,7 @@ def test_swinir_matches_reference_vectors(device, name, precision):
     meta, arr = load_golden(name)
     sd = synth_state_dict(meta)
     m = resselt_amd.load_from_state_dict(dict(sd)).to(device)
-    assert m.resolved_precision() == 'fp16'  # every fixture runs on the whole-block kernel: 'auto' is one fp16 product
+    assert m.resolved_precision() == 'mixed'  # every fixture runs on the whole-block kernel: 'auto' is the per-layer table
     m.precision = precision
     assert vars(m.parameters_info) == {k: meta['metadata'][k] for k in ('in_channels', 'out_channels', 'upscale', 'name')}
     y = m(arr['x'].to(device))
