@@ -63,7 +63,9 @@ def parse():
     ap.add_argument('--dry-run', action='store_true', help='launcher / rendezvous check without a GPU: ranks meet over gloo, rank 0 prints a stub line')
     ap.add_argument('--io', default='f32', choices=['f32', 'u8'], help='tensors crossing the boundary: fp32 [N,C,H,W] in / out, or uint8 [N,H,W,C] images in / out '
                     '(the 8-bit path: /255 and clamp*255+round inside the first / last kernel; tiles cross xGMI as bytes)')
-    ap.add_argument('--config', default='c2', choices=['c2', 'c5'], help='c2: N tiles of 1080p (weak scaling); c5: one 4320x7680 input, 2x4 tiles (strong scaling)')
+    ap.add_argument('--config', default='c2', choices=['c2', 'c3', 'c4', 'c5'],
+                    help='c2 (default, BASELINE metric): N tiles of 1080p through RealESRGAN-x4plus (weak scaling); c5: one 4320x7680 input, 2x4 tiles (strong '
+                    'scaling); c3: SPANPlus x4 fp16, 8x3x512x512 tiles, one GPU; c4: SwinIR-L x4 bf16 tensors, 1x3x1024x1024, one GPU')
     return ap.parse_args()
 
 
@@ -301,8 +303,122 @@ class PowerSampler:
                 'samples': len(rows), 'note': 'rocm-smi socket power of this GPU over the last 2 s of a 3.5 s run of back-to-back forwards (sensor averaging window ~1 s)'}  # fmt: skip
 
 
+
+SECONDARY = {
+    # BASELINE.json configs[2] / configs[3]; constants: SURVEY.md 8d (algorithmic FLOP and layer-wise bytes per OUTPUT pixel)
+    'c3': dict(metric='output megapixels/sec, SPANPlus x4 fp16, batch of 8 3x512x512 tiles, 1 MI355X', shape=(8, 3, 512, 512), io=torch.float16,
+               flop_px=53_154, bytes_px=276, workload='SPANPlus x4 (fc48, blocks [4], pixel-shuffle head), 8x3x512x512 fp16 tiles -> 8x3x2048x2048'),
+    'c4': dict(metric='output megapixels/sec, SwinIR-L x4 bf16, 3x1024x1024, 1 MI355X', shape=(1, 3, 1024, 1024), io=torch.bfloat16,
+               flop_px=3_833_694, bytes_px=27_600, workload='SwinIR-L x4 (embed 240, 9x6 blocks, 8 heads, window 8, nearest+conv, 3conv), 1x3x1024x1024 bf16 tensors -> 1x3x4096x4096'),
+}  # fmt: skip
+
+
+def secondary(args):
+    """BASELINE configs[2] (c3) and configs[3] (c4) on ONE GPU, same JSON schema as the headline: roofline of the dominant kernel measured
+    live (every distinct launch of the plan replayed alone between HIP events), the layer-wise HBM fraction, and the CPU oracle beside it."""
+    import resselt_amd
+    from resselt_amd.engine import lib as L
+    from resselt_amd.utils import synth
+
+    cfg = SECONDARY[args.config]
+    if args.gpus != 1:
+        raise SystemExit(f'--config {args.config} is a one-GPU configuration')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the engine has no CPU path')
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    if args.config == 'c3':
+        sd = synth.spanplus_state_dict(upscale=4, upsampler='ps', seed=0)
+    else:
+        sd = synth.swinir_state_dict(embed_dim=240, depths=[6] * 9, num_heads=[8] * 9, upscale=4, upsampler='nearest+conv', resi='3conv', seed=0)
+    model = resselt_amd.load_from_state_dict(dict(sd)).to(dev)
+    model.precision = args.precision
+    prec = model.resolved_precision()
+    x = synth.synth_input(cfg['shape'], seed=0).to(dev).to(cfg['io'])
+    for _ in range(max(1, args.warmup)):
+        model(x)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        y = model(x)
+    ev1.record()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    L.check_status('bench: timed region')
+    aborts = L.ring_aborts()
+    if aborts:
+        raise SystemExit(f'bench.py: {aborts} ring-schedule hand-offs timed out; the timed forwards are invalid')
+    out_px = y.shape[0] * y.shape[2] * y.shape[3]
+    kern_s = ev0.elapsed_time(ev1) / 1e3 / args.steps
+    classes = [] if args.no_kernel_roofline else kernel_classes(model, max(2, min(args.steps, 5)))
+    # the non-convolution launches that carry a price tag (the whole-block Swin kernel): one representative per distinct kernel
+    plan = model.last_plan()
+    seen: dict = {}
+    for meta, fn in ([] if args.no_kernel_roofline else plan.kernel_calls):
+        seen.setdefault(meta['kernel'], [0, meta, fn])[0] += 1
+    for count, meta, fn in seen.values():
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 3
+        classes.append({'kernel': meta['kernel'], 'launches': count, 'avg_us': round(us, 2), 'ms_per_forward': round(count * us / 1e3, 3),
+                        'flop_per_launch': round(meta['flop']), 'tflops': round(meta['flop'] / us / 1e6, 2), 'products': meta['products'],
+                        'bytes_per_launch': round(meta['bytes']), 'gbs': round(meta['bytes'] / us / 1e3, 1)})  # fmt: skip
+    classes.sort(key=lambda c: -c['ms_per_forward'])
+    flop, hbm = cfg['flop_px'] * out_px, cfg['bytes_px'] * out_px
+    res = {
+        'metric': cfg['metric'], 'value': round(out_px / 1e6 / dt, 3), 'unit': 'output megapixels/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(dt * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': {'mixed': 'fp16', 'fp16': 'fp16'}.get(prec, 'bf16'), 'data': 'synthetic',
+        'config': {'workload': cfg['workload'] + ', synthetic uniform(+-1/sqrt(fan_in)) weights', 'precision': args.precision if args.precision == prec else f'{args.precision} -> {prec}',
+                   'launches_per_step': model.launches_per_forward()},
+        'roofline_kernels': classes,
+        'roofline_frame': {'bound': 'mfma', 'achieved': round(flop / kern_s / 1e12, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                           'frac': round(flop / kern_s / 1e12 / MFMA_PEAK_TFLOPS, 4), 'note': f'{cfg["flop_px"]:,} algorithmic FLOP per output pixel (SURVEY.md 8d) / event time of a forward'},
+        'roofline_hbm': {'bound': 'hbm', 'achieved': round(hbm / kern_s / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(hbm / kern_s / 1e9 / HBM_PEAK_GBS, 4),
+                         'model': f'layer-wise bytes, {cfg["bytes_px"]:,} B per output pixel (SURVEY.md 8d)'},
+        'ring_aborts': aborts, 'event_ms_per_step': round(kern_s * 1e3, 3),
+    }  # fmt: skip
+    if classes:
+        dom = classes[0]
+        fm, fh = dom['tflops'] / MFMA_PEAK_TFLOPS, dom['gbs'] / HBM_PEAK_GBS
+        hb = fh > fm
+        res['roofline'] = {'bound': 'hbm' if hb else 'mfma', 'kernel': dom['kernel'], 'achieved': dom['gbs'] if hb else dom['tflops'],
+                           'peak': HBM_PEAK_GBS if hb else MFMA_PEAK_TFLOPS, 'unit': 'GB/s' if hb else 'TFLOP/s', 'frac': round(max(fm, fh), 4),
+                           'frac_mfma': round(fm, 4), 'frac_hbm': round(fh, 4), 'traffic': None, 'avg_launch_us': dom['avg_us'],
+                           'launches_per_forward': dom['launches'], 'flop_per_launch': dom['flop_per_launch'], 'bytes_per_launch': dom['bytes_per_launch'],
+                           'share_of_frame': round(dom['ms_per_forward'] / (kern_s * 1e3), 3)}  # fmt: skip
+    if not args.no_cpu_baseline:
+        from oracle.span import spanplus_forward
+        from oracle.swinir import swinir_forward
+
+        fwd, cshape = (spanplus_forward, (2, 3, 512, 512)) if args.config == 'c3' else (swinir_forward, (1, 3, 128, 128))
+        xc = synth.synth_input(cshape, seed=0)
+        default_threads = torch.get_num_threads()
+        torch.set_num_threads(8)
+        best = None
+        with torch.no_grad():
+            for _ in range(2):
+                t = time.perf_counter()
+                yc = fwd(sd, xc)
+                d = time.perf_counter() - t
+                best = d if best is None else min(best, d)
+        torch.set_num_threads(default_threads)
+        res['cpu_baseline'] = {'value': round(yc.shape[0] * yc.shape[2] * yc.shape[3] / 1e6 / best, 4), 'unit': 'output megapixels/s', 'cores': 8, 'kind': 'port',
+                               'sample': f'oracle ({fwd.__module__}) fp32 on a {"x".join(map(str, cshape))} sample of the workload, best of 2, {best:.2f} s, torch {torch.__version__} CPU'}  # fmt: skip
+    print(json.dumps(res), flush=True)
+
+
 def main():
     args = parse()
+    if args.config in SECONDARY:
+        return secondary(args)
     if args.gpus < 1:
         raise SystemExit('--gpus must be >= 1')
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:

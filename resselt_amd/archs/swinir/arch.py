@@ -446,7 +446,11 @@ class SwinIR(EngineModule):
             if out_planes is not None:
                 bp.out_hi, bp.out_lo = out_planes.hi_ptr(), out_planes.lo_ptr()
                 bp.out_plane_stride, bp.out_batch_stride = out_planes.plane_stride, out_planes.batch_stride
-            plan.call(lambda: L.check(lib.rsa_swin_block(C.byref(bp), C.c_void_p(ops.current_stream_ptr(dev))), 'rsa_swin_block'))
+            tokens = n * H * Wd
+            meta = dict(kernel=f'rsa::swin_block_kernel<{int(products)},{"f16" if plan.fmt == PF_F16 else "bf16"}> (whole Swin block)', products=int(products),
+                        flop=2.0 * tokens * (4 * C_ * C_ + 2 * C_ * hidden + 2 * win * win * C_),  # qkv + proj, the MLP, QK^T and PV
+                        bytes=2.0 * tokens * C_ * 4 + (0 if out_planes is None else tokens * C_ * 2.0 * (2 if out_planes.lo is not None else 1)))  # fmt: skip
+            plan.call(lambda: L.check(lib.rsa_swin_block(C.byref(bp), C.c_void_p(ops.current_stream_ptr(dev))), 'rsa_swin_block'), meta)
             plan.count_launches(1)
 
         def mlp_block(name, x_f32, out_f32, out_planes=None):

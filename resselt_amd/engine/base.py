@@ -85,6 +85,7 @@ class Plan:
         self.steps: list[Callable[[], None]] = []  # executed in order on the current stream
         self._pending: list[L.ConvParams] = []
         self.conv_arrays: list = []  # every flushed descriptor array, in launch order (bench.py replays single entries)
+        self.kernel_calls: list = []  # (meta, closure) of the non-convolution launches that carry a price tag (see ``call``)
         self.conv_cin: list = []  # per array: the layers' true input channel counts (a descriptor only knows planes of 8)
         self._pending_cin: list = []
 
@@ -120,9 +121,12 @@ class Plan:
         self.steps.append(lambda: L.conv2d_list(arr, ops.current_stream_ptr(dev)))
         return arr
 
-    def call(self, fn: Callable[[], None]) -> None:
+    def call(self, fn: Callable[[], None], meta: dict | None = None) -> None:
+        """A non-convolution launch.  ``meta`` (kernel name, algorithmic flop and bytes of the launch) lets bench.py replay and price it."""
         self.flush()
         self.steps.append(fn)
+        if meta is not None:
+            self.kernel_calls.append((meta, fn))
 
     def run(self) -> None:
         self.flush()
@@ -147,6 +151,7 @@ class Plan:
         self.keep.clear()
         self.steps.clear()
         self.conv_arrays.clear()
+        self.kernel_calls.clear()
         self.conv_cin.clear()
         self._pending = []
         self._pending_cin = []
