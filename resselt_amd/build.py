@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -35,8 +36,44 @@ def _hash() -> str:
     return h.hexdigest()
 
 
+_INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+
+
+def _deps(path: str, seen: set | None = None) -> set:
+    """``path`` and every local header it includes, transitively (``#include "..."`` resolved in csrc/ and include/)."""
+    seen = set() if seen is None else seen
+    if path in seen:
+        return seen
+    seen.add(path)
+    with open(path, encoding='utf-8', errors='replace') as fh:
+        text = fh.read()
+    for name in _INC.findall(text):
+        for base in (os.path.dirname(path), CSRC, os.path.join(ROOT, 'include')):
+            cand = os.path.normpath(os.path.join(base, name))
+            if os.path.exists(cand):
+                _deps(cand, seen)
+                break
+    return seen
+
+
+def _unit_hash(src: str) -> str:
+    """Hash of one translation unit: its source, the local headers it reaches, and this file (the compile flags)."""
+    h = hashlib.sha256()
+    for f in sorted(_deps(src)) + [os.path.abspath(__file__)]:
+        h.update(os.path.relpath(f, ROOT).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _compile(args) -> str:
     hipcc, src, obj, verbose = args
+    want = _unit_hash(src)
+    stamp = obj + '.srchash'
+    if os.path.exists(obj) and os.path.exists(stamp):
+        with open(stamp) as fh:
+            if fh.read().strip() == want:
+                return obj  # this unit and everything it includes are unchanged
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, src, '-o', obj]
     if os.path.basename(src).startswith('conv_inst_ring'):
         # SLP vectorisation packs the epilogue's f32 adds / multiplies into v_pk_* instructions, which are slower beside MFMAs
@@ -45,6 +82,8 @@ def _compile(args) -> str:
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    with open(stamp, 'w') as fh:
+        fh.write(want)
     return obj
 
 

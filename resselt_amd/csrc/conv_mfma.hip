@@ -115,8 +115,8 @@ int conv_launch(const rsa_conv_params& p, hipStream_t stream) {
   if (p.batch < 1 || p.H < 1 || p.W < 1 || p.cin_planes < 1 || p.cout < 1) return set_error(RSA_E_ARG, "conv: bad geometry");
   if (p.ksize != 1 && p.ksize != 3) return set_error(RSA_E_UNSUPPORTED, "conv: ksize must be 1 or 3");
   if (p.products != 1 && p.products != 3) return set_error(RSA_E_UNSUPPORTED, "conv: products must be 1 or 3");
-  if ((unsigned)p.in_fmt > RSA_PF_F16 || (unsigned)p.out_fmt > RSA_PF_F16 || (unsigned)p.res_fmt > RSA_PF_F16 || p.reserved0 != 0)
-    return set_error(RSA_E_ARG, "conv: in_fmt / out_fmt / res_fmt must be an rsa_plane_fmt, reserved0 zero");
+  if ((unsigned)p.in_fmt > RSA_PF_F16 || (unsigned)p.out_fmt > RSA_PF_F16 || (unsigned)p.res_fmt > RSA_PF_F16 || (unsigned)p.tile_order > 1u)
+    return set_error(RSA_E_ARG, "conv: in_fmt / out_fmt / res_fmt must be an rsa_plane_fmt, tile_order 0 or 1");
   if (conv_failure_pending()) return set_error(RSA_E_INTERNAL, "conv: an earlier ring-schedule launch reported a failed hand-off; call rsa_check_status()");
   if (p.upsample2x && (p.ksize != 3 || (p.H & 1) || (p.W & 1))) return set_error(RSA_E_UNSUPPORTED, "conv: upsample2x needs k3 and even H, W");
   if (p.in_hi == nullptr || p.w_packed == nullptr) return set_error(RSA_E_ARG, "conv: null input/weights");

@@ -227,7 +227,7 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
     };
     for (int j = (STREAMS == 2 ? g : 0); j < ntw; j += STREAMS) {
       int n, ty, tx;
-      ring_tile_coords(tile0 + j * NWG, tiles_x, tiles_y, n, ty, tx);
+      ring_tile_coords(p.tile_order ? num_tiles - 1 - (tile0 + j * NWG) : tile0 + j * NWG, tiles_x, tiles_y, n, ty, tx);
       const int y0 = ty * TH - 1, x0 = tx * TW - 1;  // halo origin in OUTPUT coordinates
       const bool interior = y0 >= 0 && x0 >= 0 && y0 + IH <= p.H && x0 + IW <= p.W;
       // source unit of the halo origin in plane 0 of this image (used by interior tiles only, where it is inside the map)
@@ -470,7 +470,7 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
     // ---- tile finished: epilogue (the loader is already streaming the next tile; the wave sharing this SIMD keeps multiplying) ----
     {
       int n, ty, tx;
-      ring_tile_coords(tile0 + j * NWG, tiles_x, tiles_y, n, ty, tx);
+      ring_tile_coords(p.tile_order ? num_tiles - 1 - (tile0 + j * NWG) : tile0 + j * NWG, tiles_x, tiles_y, n, ty, tx);
       if (!RING_DBG(8)) epilogue<NCT, CTW, NPT, OUTK>(p, acc, n, ty * TH, tx * TW, 0, wct, wpx, li, lg);
     }
 #pragma unroll

@@ -73,7 +73,7 @@ class ConvParams(C.Structure):
         ('in_fmt', C.c_int32),
         ('out_fmt', C.c_int32),
         ('res_fmt', C.c_int32),
-        ('reserved0', C.c_int32),
+        ('tile_order', C.c_int32),
     ]
 
 

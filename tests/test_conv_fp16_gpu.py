@@ -215,3 +215,39 @@ def test_failed_hand_off_is_an_error(device):
     ops.run_convs([p], device)
     torch.cuda.synchronize()
     L.check_status('after')
+
+
+@pytest.mark.parametrize(
+    'n,cin,cout,h,w,prod,fmt',
+    [
+        (2, 64, 32, 52, 75, 1, PF_F16),  # SHAPE 2, two images, ragged edges, several tiles per stream
+        (1, 192, 64, 70, 130, 1, PF_F16),  # SHAPE 1
+        (1, 48, 48, 40, 66, 1, PF_F16),  # SHAPE 3, half mode
+        (1, 96, 32, 35, 64, 3, PF_BF16),  # three products
+    ],
+)
+def test_conv_ring_reversed_tile_order(device, n, cin, cout, h, w, prod, fmt):
+    """``rsa_conv_params.tile_order = 1`` (every other layer of a serpentine plan walks the map bottom-up) changes which workgroup computes a
+    tile and when, never the tile's arithmetic: outputs are bit-identical to order 0; any other value is an argument error."""
+    x = _rand((n, cin, h, w), 11)
+    wt = _rand((cout, cin, 3, 3), 12, 1.0 / (cin * 9) ** 0.5)
+    b = _rand((cout,), 13, 0.1)
+    wts = ops.ConvWeights.from_oihw(wt, b, prod, device=device, fmt=fmt)
+    xin = tensors.nchw_to_planes(x.to(device), with_lo=prod == 3, fmt=fmt)
+    outs = []
+    for order in (0, 1):
+        o = tensors.Planes.empty(n, (cout + 7) // 8, h, w, device, with_lo=True, fmt=fmt)
+        m = tensors.empty_f32map(n, cout, h, w, device)
+        p = ops.conv_params(wts, xin, h, w, out=o, out_f32=m, act=L.ACT_LRELU, act_param=0.2)
+        p.tile_order = order
+        assert 'conv_ring' in L.conv_kernel_name(p)
+        ops.run_convs([p], device)
+        torch.cuda.synchronize()
+        assert L.ring_aborts() == 0
+        outs.append((tensors.planes_to_nchw(o, cout).cpu(), tensors.f32map_to_nchw(m, cout).cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = F.leaky_relu(_conv(x, wt, b), 0.2)
+    assert (outs[1][1] - ref).abs().max().item() <= (2e-3 if prod == 1 else 1e-4) * ref.abs().max().item()
+    p.tile_order = 2
+    with pytest.raises(RuntimeError):
+        ops.run_convs([p], device)
