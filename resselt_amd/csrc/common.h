@@ -33,8 +33,11 @@ inline bool conv_ring_eligible(const rsa_conv_params& p) {
   const bool whole = (p.cin_planes & 3) == 0;
   if (p.products == 1 && p.in_fmt != RSA_PF_F16) return false;  // plain-bf16 mode stays on the chunk-barrier kernels
   if (p.in_fmt == RSA_PF_F16 && p.upsample2x) return false;      // fp16 planes: no fused upsampling instantiated
-  if (p.out_nchw != nullptr) return ct == 3 && !p.upsample2x;  // final stores: the three-tile shape only (the pixel-shuffle heads of SPAN / Compact)
-  if (whole) return ct == 2 || ct == 4 || (ct == 3 && !p.upsample2x);
+  // final stores: the three-tile shape (the pixel-shuffle heads of SPAN / Compact) and, in three bf16 products over whole chunks, one or two
+  // cout tiles (the 64 -> 3 last convolution of RRDBNet / SwinIR's nearest+conv head: the two-stream shape, its second cout tile multiplies
+  // zero weights when Cout <= 16 -- the layer is bound by its 256 B of input per pixel, not by the matrix pipes)
+  if (p.out_nchw != nullptr) return !p.upsample2x && (ct == 3 || (ct <= 2 && whole && p.products == 3 && p.in_fmt == RSA_PF_BF16));
+  if (whole) return ct == 2 || ct == 4 || (ct == 3 && !p.upsample2x);  // (ct == 1 with plane outputs: no layer of the ten architectures has it)
   return ct == 3 && !p.upsample2x;
 }
 // Nearest x2 upsampling + 3x3 as four 2x2 phase convolutions on the source map (conv_ring_up.h): 64 -> 64 channels, LeakyReLU / none,

@@ -20,7 +20,7 @@ int conv_launch_ring(const rsa_conv_params& p, hipStream_t stream) {
   if (p.w_layout == RSA_WL_UPPHASE) return conv_launch_ring_up2(p, stream);
   const int ct = (p.cout + 15) >> 4;
   if (p.in_fmt == RSA_PF_F16) return ct == 2 ? conv_launch_ring2_f16(p, stream) : ct == 3 ? conv_launch_ring3_f16(p, stream) : conv_launch_ring1_f16(p, stream);
-  if (ct == 2) return conv_launch_ring2(p, stream);
+  if (ct <= 2) return conv_launch_ring2(p, stream);
   if (ct == 3) return conv_launch_ring3(p, stream);
   return p.upsample2x ? launch_ring<1, 1, 0>(p, stream) : launch_ring<1, 0, 0>(p, stream);
 }

@@ -95,6 +95,7 @@ const char* conv_kernel_name(const rsa_conv_params& p) {
       return ct == 2 ? "rsa::conv_ring<2,0,0,0,f16,1> (Cout<=32, one fp16 product)" : ct == 3 ? (p.out_nchw != nullptr ? "rsa::conv_ring<3,0,1,HM,f16,1> (Cout 33..48, final store, one fp16 product)" : "rsa::conv_ring<3,0,0,HM,f16,1> (Cout 33..48, one fp16 product)") : "rsa::conv_ring<1,0,0,0,f16,1> (Cout 49..64, one fp16 product)";
     if (p.in_fmt == RSA_PF_F16)
       return ct == 2 ? "rsa::conv_ring<2,0,0,0,f16,3> (Cout<=32, three fp16 products)" : ct == 3 ? (p.out_nchw != nullptr ? "rsa::conv_ring<3,0,1,HM,f16,3> (Cout 33..48, final store, three fp16 products)" : "rsa::conv_ring<3,0,0,HM,f16,3> (Cout 33..48, three fp16 products)") : "rsa::conv_ring<1,0,0,0,f16,3> (Cout 49..64, three fp16 products)";
+    if (ct <= 2 && p.out_nchw != nullptr) return "rsa::conv_ring<2,0,1> (Cout<=32, final store)";
     return ct == 2 ? "rsa::conv_ring<2,UP,0> (Cout<=32)" : ct == 3 ? (p.out_nchw != nullptr ? "rsa::conv_ring<3,0,1,HM> (Cout 33..48, final store)" : "rsa::conv_ring<3,0,0,HM> (Cout 33..48)") : "rsa::conv_ring<1,UP,0> (Cout 49..64)";
   }
   if (p.ksize == 1 && p.cout >= 96 && p.out_nchw == nullptr) return "rsa::gemm_k1_kernel";

@@ -351,3 +351,34 @@ def test_conv_upsample_as_four_phase_kernels(device, n, h, w):
     ops.run_convs([p2], device)
     torch.cuda.synchronize()
     assert (tensors.planes_to_nchw(out2, 64).cpu() - got).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('cout,dtype,ps', [(3, torch.float32, 1), (3, torch.uint8, 1), (12, torch.float16, 2), (32, torch.bfloat16, 1)])
+def test_conv_ring_final_store_small_cout(device, cout, dtype, ps):
+    """The last convolution of RRDBNet / SwinIR's nearest+conv head (64 -> 3, archs/esrgan/arch.py:120-126 of the reference) on the two-stream
+    ring shape with a final store (round 3): plain tensor of any dtype, 8-bit image, depth-to-space; Cout <= 16 leaves the second cout tile
+    multiplying zero weights.  Several tiles per stream, ragged edges, two images."""
+    n, cin, h, w = 2, 64, 70, 150
+    x = _rand((n, cin, h, w), 21)
+    wt = _rand((cout, cin, 3, 3), 22, 1.0 / (cin * 9) ** 0.5)
+    b = _rand((cout,), 23, 0.1) + (0.5 if dtype == torch.uint8 else 0.0)
+    ref = _ref_conv(x, wt, b)
+    wts = ops.ConvWeights.from_oihw(wt, b, 3, device=device)
+    xin = tensors.nchw_to_planes(x.to(device), with_lo=True)
+    oc = cout // (ps * ps)
+    shape = (n, h * ps, w * ps, oc) if dtype == torch.uint8 else (n, oc, h * ps, w * ps)
+    out = torch.empty(shape, dtype=dtype, device=device)
+    p = ops.conv_params(wts, xin, h, w, out_nchw=out, pixel_shuffle=ps)
+    assert 'conv_ring<2,0,1>' in L.conv_kernel_name(p)
+    ops.run_convs([p], device)
+    torch.cuda.synchronize()
+    assert L.ring_aborts() == 0
+    if ps > 1:
+        ref = F.pixel_shuffle(ref, ps)
+    if dtype == torch.uint8:
+        want = (ref.clamp(0, 1) * 255).round().permute(0, 2, 3, 1)
+        diff = (out.cpu().float() - want).abs()
+        assert diff.max().item() <= 1 and (diff > 0).float().mean().item() < 1e-3  # a rounding tie broken by the 1e-6 arithmetic difference
+    else:
+        tol = {torch.float32: 2e-5, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
+        assert (out.cpu().float() - ref).abs().max().item() <= tol * ref.abs().max().item()
