@@ -2,6 +2,10 @@ import os, sys, statistics, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
+from resselt_amd.engine import lib as L
+if os.environ.get('RSA_LIB'):
+    _p = os.path.abspath(os.environ['RSA_LIB'])
+    L.lib_path = lambda: _p  # an experiment build (tools/variant.sh)
 import resselt_amd
 from resselt_amd.utils import synth
 dev = torch.device('cuda:0')
