@@ -36,6 +36,9 @@ def drct_hparams(sd: Mapping[str, torch.Tensor]) -> dict:
 def rdg_forward(sd, pre: str, x: torch.Tensor, H: int, W: int, window: int, num_heads: int) -> torch.Tensor:
     """RDG.forward (drct/arch.py:322-329): five Swin blocks over a growing concatenation, 1x1 'adjust' convs, x5 * 0.2 + x."""
     B, L, C = x.shape
+    # a checkpoint saved without the attn_mask buffers loads with img_size = window (drct/__init__.py:78-82), and a block whose
+    # input_resolution <= window drops its shift (drct/arch.py:373-376): swin2 / swin4 then run unshifted
+    shifted = f'{pre}.swin2.attn_mask' in sd
 
     def adjust(j, t):  # pe(lrelu(adjust_j(pue(t)))): tokens -> image -> 1x1 conv -> tokens
         img = t.transpose(1, 2).reshape(B, t.shape[2], H, W)
@@ -46,7 +49,7 @@ def rdg_forward(sd, pre: str, x: torch.Tensor, H: int, W: int, window: int, num_
         cat = torch.cat(feats, -1)
         dim = cat.shape[-1]
         heads = num_heads - (dim % num_heads) if j > 1 else num_heads  # drct/arch.py:241, 256, 271, 286
-        shift = window // 2 if j in (2, 4) else 0
+        shift = window // 2 if j in (2, 4) and shifted else 0
         out = adjust(j, swin_block(sd, f'{pre}.swin{j}', cat, H, W, window, shift, heads))
         if j < 5:
             out = F.leaky_relu(out, 0.2)

@@ -23,6 +23,7 @@ import torch
 
 from ...engine import lib as L
 from ...engine import ops
+from ...engine.tensors import Planes
 from ...engine.base import EngineModule, Plan
 from ...engine.paramtree import build_param_tree
 from ..dat.arch import bias_fragments
@@ -131,8 +132,13 @@ class DRCT(EngineModule):
             raise NotImplementedError('embed_dim and gc must be multiples of 4 (channel groups of the f32 token map)')
         if window_size * window_size > 256:
             raise NotImplementedError('window must hold at most 256 tokens')
-        if img_size <= window_size:
-            raise NotImplementedError('img_size <= window_size changes the block geometry; not supported')
+        if img_size < window_size:
+            raise NotImplementedError('img_size < window_size shrinks the window (and its bias table) to the image size; not supported')
+        # img_size == window_size is what the loader passes for a checkpoint saved without attn_mask buffers (drct/__init__.py:78-82 of the
+        # reference): a block whose input_resolution <= window drops its shift (drct/arch.py:373-376), so swin2 / swin4 run unshifted
+        self.unshifted = img_size == window_size
+        if resi_connection not in ('1conv', 'identity'):
+            raise NotImplementedError(f"resi_connection must be '1conv' or 'identity', got {resi_connection!r}")
         num_heads = list(num_heads)
         for nh in num_heads:
             for dim, heads, _, _ in block_dims(embed_dim, gc, nh):
@@ -181,26 +187,46 @@ class DRCT(EngineModule):
                 W[f'{b}.bias_frag'] = bias_fragments(dense.reshape(n, n, heads).permute(2, 0, 1).contiguous())
                 conv(f'layers.{i}.adjust{j}')
         ln('norm')
+        if self.resi == 'identity':  # nn.Identity as a 1x1 convolution (see _build_plan)
+            eye = torch.eye(self.embed_dim, dtype=torch.float32, device=device)[:, :, None, None]
+            W['identity'] = ops.ConvWeights.from_oihw(eye, torch.zeros(self.embed_dim, dtype=torch.float32, device=device), products, device=device)
         for name in ('conv_after_body', 'conv_before_upsample.0', 'upsample.0', 'upsample.2', 'upsample.4', 'conv_last'):
             if f'{name}.weight' in sd:
                 conv(name)
         W['mean'] = torch.tensor(RGB_MEAN if self.in_chans == 3 else [0.0] * self.in_chans, dtype=torch.float32, device=device)
         return W
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """A batch runs image by image through the one-image plan (the dense concatenation of a group is addressed by channel-group
-        offsets inside ONE image's token map); the reference's `forward` (archs/drct/arch.py:756-792) is per-image arithmetic throughout."""
-        if x.dim() == 4 and x.shape[0] > 1:
-            return torch.cat([super(DRCT, self).forward(x[i : i + 1]) for i in range(x.shape[0])], 0)
-        return super().forward(x)
+    def macs_per_input_pixel(self) -> int:
+        """Algorithmic multiply-accumulates per pixel of the (window-padded) input grid: Linear layers, QK^T + PV over a window, the 1x1
+        adjust convolutions, and the convolutions of the head at their own resolution."""
+        C_, gc, n_tok = self.embed_dim, self.gc, self.window_size**2
+        total = 9 * self.in_chans * C_
+        for nh in self.num_heads:
+            for j, (dim, heads, _, full_mlp) in enumerate(block_dims(C_, gc, nh), start=1):
+                hidden = int(dim * (self.mlp_ratio if full_mlp else 1))
+                total += 4 * dim * dim + 2 * n_tok * dim + 2 * dim * hidden + dim * (gc if j < 5 else C_)
+        if self.resi == '1conv':
+            total += 9 * C_ * C_
+        total += 9 * C_ * 64
+        res = 1
+        if self.upscale == 3:
+            total += 9 * 64 * 9 * 64
+            res = 9
+        else:
+            for _ in range(int(math.log2(self.upscale))):
+                total += 9 * 64 * 4 * 64 * res
+                res *= 4
+        return total + 9 * 64 * self.in_chans * res
 
     # ---------------------------------------------------------------- plan
     def _build_plan(self, plan: Plan, W, x_shape, dtype, products):
-        n, c, h0, w0 = x_shape
+        """One plan per input signature.  The dense concatenation of a group is addressed by channel-group views inside ONE image's token
+        map, so a batch is the per-image launch list repeated over the images of the batch, all sharing one set of intermediate buffers
+        (the launches of a plan run in order on one stream); only the input planes and the output tensor are per image."""
+        nb, c, h0, w0 = x_shape
         if c != self.in_chans:
             raise RuntimeError(f'model expects {self.in_chans} input channels, got {c}')
-        if n != 1:
-            raise NotImplementedError('a DRCT plan holds one image (forward() splits batches)')
+        n = 1  # images per launch
         win = self.window_size
         H, Wd = h0 + (win - h0 % win) % win, w0 + (win - w0 % win) % win
         if H - h0 >= h0 or Wd - w0 >= w0:
@@ -210,14 +236,13 @@ class DRCT(EngineModule):
         with_lo = products == 3
         dev = plan.device
         lib = L.load()
-        HW = H * Wd
 
-        x_pl = plan.planes(n, (c + 7) // 8, H, Wd, with_lo)
+        x_all = plan.planes(nb, (c + 7) // 8, H, Wd, with_lo)
         mean = W['mean']
 
         def set_input(x):
             # (x - mean) * img_range and check_img_size's reflect padding (arch.py:765-776), fused into the layout kernel
-            ops.nchw_to_planes(x, x_pl, mean, self.img_range)
+            ops.nchw_to_planes(x, x_all, mean, self.img_range)
 
         first = plan.f32map(n, C_, H, Wd)
         cat = [plan.f32map(n, wide, H, Wd) for _ in range(2)]  # dense concatenation of a group: x | x1 | x2 | x3 | x4
@@ -229,6 +254,19 @@ class DRCT(EngineModule):
         hid_pl = plan.planes(n, (int(wide * max(self.mlp_ratio, 1.0)) + 7) // 8, H, Wd, with_lo)
         t_pl = plan.planes(n, (wide + 7) // 8, H, Wd, with_lo)  # a block's output as planes (input of its adjust convolution)
         body_pl = plan.planes(n, (C_ + 7) // 8, H, Wd, with_lo)
+        y0_pl = plan.planes(n, 8, H, Wd, with_lo)
+        # the pixel-shuffle stages of the head: a plain tensor the final store writes, re-laid out as planes for the next convolution
+        stages = []
+        hh, ww, i = H, Wd, 0
+        while f'upsample.{i}' in W:
+            r = math.isqrt(W[f'upsample.{i}'].cout // 64)
+            shuffled = torch.empty((n, 64, hh * r, ww * r), dtype=torch.float32, device=dev)
+            plan.keep.append(shuffled)
+            hh, ww = hh * r, ww * r
+            stages.append((f'upsample.{i}', r, shuffled, plan.planes(n, 8, hh, ww, with_lo)))
+            i += 2
+        if self.resi == 'identity' and 'identity' not in W:
+            raise RuntimeError('packed weights lack the identity layer')  # (_pack adds it)
 
         def chan_view(m: torch.Tensor, c0: int, cn: int) -> torch.Tensor:
             """Channels [c0, c0 + cn) of an f32 token map as a map of their own (one image: groups are contiguous)."""
@@ -262,72 +300,73 @@ class DRCT(EngineModule):
             """conv_params with f32 operands that are channel views of wider maps: checked against the view, passed by pointer."""
             return ops.conv_params(wts, src, H, Wd, **kw)
 
-        plan.conv(ops.conv_params(W['conv_first'], x_pl, H, Wd, out_f32=first))
-        cur = cat[0]
-        if self.patch_norm:
-            layernorm('patch_embed.norm', first, C_, out_f32=chan_view(cur, 0, C_))
-        else:
-            plan.call(lambda dst=chan_view(cur, 0, C_): dst.copy_(first))
-        ci = 0
-        for i in range(self.num_layers):
-            cur, nxt = cat[ci], cat[ci ^ 1]
-            for j, (dim, heads, shifted, full_mlp) in enumerate(block_dims(C_, gc, self.num_heads[i]), start=1):
-                b = f'layers.{i}.swin{j}'
-                chunks = -(-(dim // heads) // 32)
-                hp = heads * 32 * chunks // 8
-                cp = (dim + 7) // 8
-                hidden = int(dim * (self.mlp_ratio if full_mlp else 1))
-                xin = chan_view(cur, 0, dim)
-                layernorm(f'{b}.norm1', xin, dim, out_planes=a_pl)
-                plan.conv(ops.conv_params(W[f'{b}.attn.qkv'], a_pl, H, Wd, cin_planes=cp, out=qkv_pl))
-                attention(b, heads, chunks, shifted)
-                x1 = chan_view(blk[0], 0, dim)
-                plan.conv(f32_view_conv(W[f'{b}.attn.proj'], o_pl, cin_planes=hp, res1=xin, alpha=1.0, out_f32=x1))
-                layernorm(f'{b}.norm2', x1, dim, out_planes=a_pl)
-                plan.conv(ops.conv_params(W[f'{b}.mlp.fc1'], a_pl, H, Wd, cin_planes=cp, act=L.ACT_GELU, out=hid_pl))
-                plan.conv(f32_view_conv(W[f'{b}.mlp.fc2'], hid_pl, cin_planes=(hidden + 7) // 8, res1=x1, alpha=1.0, out=t_pl))
-                # adjust_j (1x1) on the block's output: x_j = lrelu(.) stored at channel offset dim of the concatenation;
-                # adjust_5 closes the group: x5 * 0.2 + x into the first C_ channels of the next group's concatenation
-                if j < 5:
-                    plan.conv(f32_view_conv(W[f'layers.{i}.adjust{j}'], t_pl, cin_planes=cp, act=L.ACT_LRELU, act_param=0.2, out_f32=chan_view(cur, dim, gc)))
-                else:
-                    plan.conv(f32_view_conv(W[f'layers.{i}.adjust{j}'], t_pl, cin_planes=cp, res1=chan_view(cur, 0, C_), alpha=0.2, out_f32=chan_view(nxt, 0, C_)))
-            ci ^= 1
-        cur = cat[ci]
-        layernorm('norm', chan_view(cur, 0, C_), C_, out_planes=a_pl)
-        cp0 = (C_ + 7) // 8
-        if self.resi == '1conv':
-            plan.conv(ops.conv_params(W['conv_after_body'], a_pl, H, Wd, cin_planes=cp0, res1=first, alpha=1.0, out=body_pl))
-        else:
-            raise NotImplementedError("resi_connection='identity' (norm output + conv_first as planes) is not built")
-
-        out_shape = (n, self.in_chans, H * s, Wd * s)
-        out_buf = {'y': torch.empty(out_shape, dtype=dtype, device=dev)}
+        out_shape = (nb, self.in_chans, H * s, Wd * s)
+        out_buf: dict = {}
         final = dict(out_scale=1.0 / self.img_range, out_shift=mean)  # x / img_range + mean (arch.py:790)
-        y = plan.planes(n, 8, H, Wd, with_lo)
-        plan.conv(ops.conv_params(W['conv_before_upsample.0'], body_pl, H, Wd, cin_planes=cp0, act=L.ACT_LRELU, act_param=0.01, out=y))
-        hh, ww = H, Wd
-        i = 0
-        while f'upsample.{i}' in W:
-            r = math.isqrt(W[f'upsample.{i}'].cout // 64)
-            shuffled = torch.empty((n, 64, hh * r, ww * r), dtype=torch.float32, device=dev)
-            plan.keep.append(shuffled)
-            plan.conv(ops.conv_params(W[f'upsample.{i}'], y, hh, ww, out_nchw=shuffled, pixel_shuffle=r))
-            hh, ww = hh * r, ww * r
-            ny = plan.planes(n, 8, hh, ww, with_lo)
-            plan.call(lambda src=shuffled, dst=ny: ops.nchw_to_planes(src, dst))
-            y = ny
-            i += 2
-        plan.conv(ops.conv_params(W['conv_last'], y, hh, ww, out_nchw=out_buf['y'], **final))
-        arr = plan.flush()
-        last_entry = arr[len(arr) - 1]
+        last_entries = []  # (descriptor of an image's last convolution, image index)
 
+        def image(bi: int) -> None:
+            x_pl = Planes(x_all.hi[bi : bi + 1], None if x_all.lo is None else x_all.lo[bi : bi + 1])
+            plan.conv(ops.conv_params(W['conv_first'], x_pl, H, Wd, out_f32=first))
+            cur = cat[0]
+            if self.patch_norm:
+                layernorm('patch_embed.norm', first, C_, out_f32=chan_view(cur, 0, C_))
+            else:
+                plan.call(lambda dst=chan_view(cur, 0, C_): dst.copy_(first))
+            ci = 0
+            for i in range(self.num_layers):
+                cur, nxt = cat[ci], cat[ci ^ 1]
+                for j, (dim, heads, shifted, full_mlp) in enumerate(block_dims(C_, gc, self.num_heads[i]), start=1):
+                    b = f'layers.{i}.swin{j}'
+                    chunks = -(-(dim // heads) // 32)
+                    hp = heads * 32 * chunks // 8
+                    cp = (dim + 7) // 8
+                    hidden = int(dim * (self.mlp_ratio if full_mlp else 1))
+                    xin = chan_view(cur, 0, dim)
+                    layernorm(f'{b}.norm1', xin, dim, out_planes=a_pl)
+                    plan.conv(ops.conv_params(W[f'{b}.attn.qkv'], a_pl, H, Wd, cin_planes=cp, out=qkv_pl))
+                    attention(b, heads, chunks, shifted and not self.unshifted)
+                    x1 = chan_view(blk[0], 0, dim)
+                    plan.conv(f32_view_conv(W[f'{b}.attn.proj'], o_pl, cin_planes=hp, res1=xin, alpha=1.0, out_f32=x1))
+                    layernorm(f'{b}.norm2', x1, dim, out_planes=a_pl)
+                    plan.conv(ops.conv_params(W[f'{b}.mlp.fc1'], a_pl, H, Wd, cin_planes=cp, act=L.ACT_GELU, out=hid_pl))
+                    plan.conv(f32_view_conv(W[f'{b}.mlp.fc2'], hid_pl, cin_planes=(hidden + 7) // 8, res1=x1, alpha=1.0, out=t_pl))
+                    # adjust_j (1x1) on the block's output: x_j = lrelu(.) stored at channel offset dim of the concatenation;
+                    # adjust_5 closes the group: x5 * 0.2 + x into the first C_ channels of the next group's concatenation
+                    if j < 5:
+                        plan.conv(f32_view_conv(W[f'layers.{i}.adjust{j}'], t_pl, cin_planes=cp, act=L.ACT_LRELU, act_param=0.2, out_f32=chan_view(cur, dim, gc)))
+                    else:
+                        plan.conv(f32_view_conv(W[f'layers.{i}.adjust{j}'], t_pl, cin_planes=cp, res1=chan_view(cur, 0, C_), alpha=0.2, out_f32=chan_view(nxt, 0, C_)))
+                ci ^= 1
+            cur = cat[ci]
+            layernorm('norm', chan_view(cur, 0, C_), C_, out_planes=a_pl)
+            cp0 = (C_ + 7) // 8
+            # conv_after_body(forward_features(x)) + conv_first(x) (arch.py:781): a 3x3 convolution, or nn.Identity (arch.py:731-732) -- the
+            # latter as a 1x1 convolution with the identity matrix, whose epilogue adds conv_first's map and writes the planes the head reads
+            plan.conv(ops.conv_params(W['conv_after_body' if self.resi == '1conv' else 'identity'], a_pl, H, Wd, cin_planes=cp0, res1=first, alpha=1.0, out=body_pl))
+            plan.conv(ops.conv_params(W['conv_before_upsample.0'], body_pl, H, Wd, cin_planes=cp0, act=L.ACT_LRELU, act_param=0.01, out=y0_pl))
+            y, hh, ww = y0_pl, H, Wd
+            for name, r, shuffled, ny in stages:
+                plan.conv(ops.conv_params(W[name], y, hh, ww, out_nchw=shuffled, pixel_shuffle=r))
+                hh, ww = hh * r, ww * r
+                plan.call(lambda src=shuffled, dst=ny: ops.nchw_to_planes(src, dst))
+                plan.count_launches(1)
+                y = ny
+            placeholder = torch.empty((n,) + out_shape[1:], dtype=dtype, device=dev)  # (never written: prepare_output patches the pointer first)
+            plan.conv(ops.conv_params(W['conv_last'], y, hh, ww, out_nchw=placeholder, **final))
+            arr = plan.flush()
+            last_entries.append((arr[len(arr) - 1], bi))
+
+        for bi in range(nb):
+            image(bi)
+
+        # a fresh output tensor per call: every image's last descriptor is pointed at its slice
         def prepare_output():
-            if 'y' not in out_buf:
-                out_buf['y'] = torch.empty(out_shape, dtype=dtype, device=dev)
-            last_entry.out_nchw = out_buf['y'].data_ptr()
+            out_buf['y'] = torch.empty(out_shape, dtype=dtype, device=dev)
+            for e, bi in last_entries:
+                e.out_nchw = out_buf['y'][bi : bi + 1].data_ptr()
 
-        plan.steps.insert(len(plan.steps) - 1, prepare_output)
+        plan.steps.insert(0, prepare_output)
 
         def get_output():
             return out_buf.pop('y')[:, :, : h0 * s, : w0 * s]

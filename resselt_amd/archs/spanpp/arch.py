@@ -112,7 +112,7 @@ class SpanPP(EngineModule):
         return state_dict
 
     def _pack(self, device, products):
-        sd = {k: v.detach().to(device=device) for k, v in self.state_dict().items()}
+        sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}  # folds and the IGConv kernel are host-side weight preprocessing (f64 / f32)
         fsd = {k: (v.to(torch.float32) if v.is_floating_point() else v) for k, v in sd.items()}
         W = {}
         for name in self._rep_names:

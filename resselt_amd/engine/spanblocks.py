@@ -134,7 +134,9 @@ def span_layer_policy(name: str, conv3xc: bool) -> tuple[int, int]:
 
 
 def pack_span_family(module, device, products: int, conv3xc_names: list[str], plain_names: list[str]) -> dict:
-    sd = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in module.state_dict().items()}
+    # The re-parameterisation is weight preprocessing on ~100 KB of tensors: it runs on the HOST in f64 (no vendor GEMM / reduction kernel is
+    # launched from inside the package); ConvWeights.from_oihw uploads the folded f32 kernel and packs it with rsa_pack_weights.
+    sd = {k: v.detach().to(device='cpu', dtype=torch.float32) for k, v in module.state_dict().items()}
     mixed = getattr(products, 'name', '') == 'mixed'
     W = {}
     for name in conv3xc_names:

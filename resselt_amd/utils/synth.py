@@ -555,7 +555,7 @@ def drct_block_dims(embed_dim: int, gc: int, num_heads: int):
 
 
 def drct_state_dict(in_chans=3, embed_dim=180, num_layers=2, num_heads=6, window=16, mlp_ratio=2.0, gc=32, upscale=2, resi='1conv', img_size=64,
-                    seed=0):  # fmt: skip
+                    seed=0, attn_mask=True):  # fmt: skip
     """Keys of the reference DRCT module (archs/drct/arch.py:617-792) incl. its registered buffers (relative_position_index, attn_mask of
     the shifted blocks swin2 / swin4).  The loader fixes depths = (6,) * num_layers and reads one head count per layer."""
     sd: OrderedDict = OrderedDict()
@@ -594,7 +594,7 @@ def drct_state_dict(in_chans=3, embed_dim=180, num_layers=2, num_heads=6, window
         for j, (dim, heads, shifted) in enumerate(drct_block_dims(C, gc, num_heads), start=1):
             b = f'layers.{i}.swin{j}'
             hidden = int(dim * (mlp_ratio if j <= 3 else 1))
-            if shifted:
+            if shifted and attn_mask:  # (a checkpoint saved without the mask buffers loads as img_size = window: no block is shifted)
                 sd[f'{b}.attn_mask'] = shift_mask()
             ln(f'{b}.norm1', dim)
             sd[f'{b}.attn.relative_position_bias_table'] = synth_tensor(f'{b}.attn.relative_position_bias_table', ((2 * window - 1) ** 2, heads), 16, seed)

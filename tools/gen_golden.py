@@ -237,6 +237,10 @@ def drct_cases():
         ('drct_x2_e180_g32_l1_40x50', dict(num_layers=1, upscale=2), (1, 3, 40, 50), 201),
         ('drct_x4_e180_g32_l2_48x64', dict(num_layers=2, upscale=4), (1, 3, 48, 64), 202),
         ('drct_x3_e60_g16_w8_l2_33x33', dict(embed_dim=60, gc=16, window=8, num_layers=2, upscale=3, mlp_ratio=4.0), (1, 3, 33, 33), 203),
+        # resi_connection='identity' (no conv_after_body: drct/arch.py:731-732), a batch of two
+        ('drct_x2_e60_g16_w8_identity_b2_24x40', dict(embed_dim=60, gc=16, window=8, num_layers=1, upscale=2, resi='identity'), (2, 3, 24, 40), 204),
+        # a checkpoint without attn_mask buffers: the loader passes img_size = window and no block is shifted (drct/arch.py:373-376)
+        ('drct_x2_e60_g16_w8_nomask_32x24', dict(embed_dim=60, gc=16, window=8, num_layers=1, upscale=2, attn_mask=False), (1, 3, 32, 24), 205),
     ]
     for name, kw, shape, seed in cases:
         sd = synth.drct_state_dict(seed=seed, **kw)
