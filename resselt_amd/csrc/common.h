@@ -40,6 +40,24 @@ inline bool conv_ring_eligible(const rsa_conv_params& p) {
   if (whole) return ct == 2 || ct == 4 || (ct == 3 && !p.upsample2x);  // (ct == 1 with plane outputs: no layer of the ten architectures has it)
   return ct == 3 && !p.upsample2x;
 }
+// conv5 of a residual dense block in the one-product fp16 mode (conv_ring.h, XRES): four cout tiles, whole chunks, hi + lo plane output, and
+// residual 1 = the first 64 channels of the layer's own input planes (hi + lo; an optional second plane residual), nothing else in the
+// epilogue.  RSA_RING_XRES=0 in the environment switches the form off (A/B runs).
+bool conv_ring_xres_enabled();
+inline bool conv_ring_xres_eligible(const rsa_conv_params& p) {
+  return p.ksize == 3 && p.products == 1 && p.in_fmt == RSA_PF_F16 && !p.upsample2x && p.cout == 64 && p.cin_planes >= 8 && (p.cin_planes & 3) == 0 &&
+         p.out_nchw == nullptr && p.out_f32 == nullptr && p.res1 == nullptr && p.res2 == nullptr && p.out_hi != nullptr && p.out_lo != nullptr &&
+         p.out_fmt == RSA_PF_F16 && p.res_fmt == RSA_PF_F16 && p.res1_hi != nullptr && p.res1_lo != nullptr && p.res1_hi == p.in_hi &&
+         p.res_plane_stride == p.in_plane_stride && p.res_batch_stride == p.in_batch_stride && (p.res2_hi == nullptr || p.res2_lo != nullptr) &&
+         (p.act == RSA_ACT_NONE || (p.act == RSA_ACT_LRELU && p.act_param >= 0.f && p.act_param <= 1.f));
+}
+// The growth convolutions of a dense block in the one-product fp16 mode: hi-only fp16 plane output, LeakyReLU (slope in [0, 1]) or no
+// activation, whole cout tiles, no residual, no f32 map (conv_ring.h, XRES 2: the epilogue shape EM 1 called directly).
+inline bool conv_ring_em1_eligible(const rsa_conv_params& p) {
+  return p.products == 1 && p.in_fmt == RSA_PF_F16 && p.out_fmt == RSA_PF_F16 && p.out_nchw == nullptr && p.out_f32 == nullptr && p.out_hi != nullptr &&
+         p.out_lo == nullptr && p.res1 == nullptr && p.res2 == nullptr && p.res1_hi == nullptr && p.res2_hi == nullptr && (p.cout & 15) == 0 &&
+         (p.act == RSA_ACT_NONE || (p.act == RSA_ACT_LRELU && p.act_param >= 0.f && p.act_param <= 1.f));
+}
 // Nearest x2 upsampling + 3x3 as four 2x2 phase convolutions on the source map (conv_ring_up.h): 64 -> 64 channels, LeakyReLU / none,
 // split-plane output only -- the upconv layers of RRDBNet and of SwinIR's nearest+conv head.  RSA_CONV_UP2=0 switches it off (A/B runs).
 bool conv_up2_enabled();

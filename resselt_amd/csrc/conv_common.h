@@ -204,9 +204,14 @@ struct GeoLW {
 //   EM 2: EM 1 + residual 1 as split planes (hi + lo) -- conv5 of a residual dense block;   EM 3: EM 2 + residual 2 (the RRDB's)
 // PF = plane format of the outputs and residuals of EM 1 / 2 (the generic body reads p.out_fmt / p.res_fmt).  With PF = fp16, EM 1
 // writes hi ONLY (the one-product consumers never read lo); EM 2 keeps hi + lo (the residual stream: 22 bits).
-template <int NCT, int CTW, int NPT, int OUTK, int AC, int EM = 0, int PF = 0>
+// XL 1 (EM 2 / 3 only; conv_ring.h's XRES kernels): residual 1 is the first 64 channels of the layer's own INPUT (conv5 of a residual dense
+// block: x5 * 0.2 + x), whose hi halves are still in the ring slots `xslots` (4 bits per 16-channel half chunk) of the LDS array `x_lds` --
+// they are read from there (slot geometry: units per slot / per plane / per halo row) instead of a second time from memory; lo halves come
+// from res1_lo as before.
+template <int NCT, int CTW, int NPT, int OUTK, int AC, int EM = 0, int PF = 0, int XL = 0>
 __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f32x4 (&acc)[NPT][CTW], int n, int y0, int x0, int slab, int wct,
-                                              int wpx, int li, int lg) {
+                                              int wpx, int li, int lg, const uint4* x_lds = nullptr, uint32_t xslots = 0u, int x_slot = 0,
+                                              int x_ps = 0, int x_iw = 0) {
   constexpr int RPW = NPT / 2;
   constexpr bool G = EM == 0;
   const bool R1F = G && p.res1 != nullptr, R2F = G && p.res2 != nullptr;                          // residuals as f32 maps
@@ -306,7 +311,11 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
 #ifndef RSA_EPI_PD
 #define RSA_EPI_PD 3
 #endif
-  constexpr int PD = EM == 2 ? RSA_EPI_PD : (EM == 3 ? (RSA_EPI_PD + 1) / 2 : 0);
+#ifndef RSA_EPI_PDX
+#define RSA_EPI_PDX 1  // XL: the hi halves come from LDS at their use, only lo halves (and the second residual) are fetched ahead; one step
+                       // ahead measured best (deeper: the raw values spill; profiles/r03_i_conv5_epilogue_prefetch.txt)
+#endif
+  constexpr int PD = XL ? RSA_EPI_PDX : (EM == 2 ? RSA_EPI_PD : (EM == 3 ? (RSA_EPI_PD + 1) / 2 : 0));
   constexpr int NSTEPS_E = CTW * RPW;
   uint2 rb1h[PD + 1][2], rb1l[PD + 1][2], rb2h[EM == 3 ? PD + 1 : 1][2], rb2l[EM == 3 ? PD + 1 : 1][2];
   auto fetch_raw = [&](int s) {
@@ -324,7 +333,7 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
       rb1h[slot][e] = rb1l[slot][e] = make_uint2(0u, 0u);
       if (EM == 3) rb2h[slot][e] = rb2l[slot][e] = make_uint2(0u, 0u);
       if (okl) {
-        rb1h[slot][e] = *(const uint2*)((const char*)p.res1_hi + runit0 * 16 + poff);
+        if (!XL) rb1h[slot][e] = *(const uint2*)((const char*)p.res1_hi + runit0 * 16 + poff);  // (XL: read from the ring at its use, below)
         rb1l[slot][e] = *(const uint2*)((const char*)p.res1_lo + runit0 * 16 + poff);
         if (EM == 3) {
           rb2h[slot][e] = *(const uint2*)((const char*)p.res2_hi + runit0 * 16 + poff);
@@ -372,6 +381,13 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
           if (s + PD < NSTEPS_E) fetch_raw(s + PD);
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
+            if (XL) {  // the hi halves of x: ring slot of the half chunk (plane >> 1), plane & 1 inside it, halo coordinates (row + 1, column + 1)
+              const int pt = pp * 2 + e;
+              const int plane = (cbase >> 3) + (lg >> 1);
+              const uint32_t u = ((xslots >> (4 * (plane >> 1))) & 15u) * (uint32_t)x_slot + (uint32_t)((plane & 1) * x_ps) +
+                                 (uint32_t)((wpx * RPW + (pt >> 1) + 1) * x_iw + (pt & 1) * 16 + li + 1);
+              rb1h[s % (PD + 1)][e] = *(const uint2*)((const char*)x_lds + u * 16u + (uint32_t)(lg & 1) * 8u);
+            }
             cr1[e] = widen(rb1h[s % (PD + 1)][e], rb1l[s % (PD + 1)][e]);
             cr2[e] = EM == 3 ? widen(rb2h[EM == 3 ? s % (PD + 1) : 0][e], rb2l[EM == 3 ? s % (PD + 1) : 0][e]) : (f32x4){0.f, 0.f, 0.f, 0.f};
           }

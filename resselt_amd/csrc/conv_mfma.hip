@@ -77,6 +77,13 @@ bool conv_up2_enabled() {
   }();
   return on;
 }
+bool conv_ring_xres_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("RSA_RING_XRES");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  return on;
+}
 bool conv_ring_enabled() {
   static const bool on = [] {
     const char* e = getenv("RSA_CONV_RING");
@@ -91,8 +98,10 @@ const char* conv_kernel_name(const rsa_conv_params& p) {
   if (p.w_layout == RSA_WL_UPPHASE) return "rsa::conv_ring_up2 (x2 upsampling as four 2x2 phases)";
   if (p.w_layout != RSA_WL_TAPS) {
     const int ct = (p.cout + 15) >> 4;
-    if (p.products == 1)
+    if (p.products == 1) {
+      if (ct == 4 && conv_ring_xres_enabled() && conv_ring_xres_eligible(p)) return "rsa::conv_ring<1,0,0,0,f16,1,XRES> (conv5 of a dense block, one fp16 product, residual hi halves from the ring)";
       return ct == 2 ? "rsa::conv_ring<2,0,0,0,f16,1> (Cout<=32, one fp16 product)" : ct == 3 ? (p.out_nchw != nullptr ? "rsa::conv_ring<3,0,1,HM,f16,1> (Cout 33..48, final store, one fp16 product)" : "rsa::conv_ring<3,0,0,HM,f16,1> (Cout 33..48, one fp16 product)") : "rsa::conv_ring<1,0,0,0,f16,1> (Cout 49..64, one fp16 product)";
+    }
     if (p.in_fmt == RSA_PF_F16)
       return ct == 2 ? "rsa::conv_ring<2,0,0,0,f16,3> (Cout<=32, three fp16 products)" : ct == 3 ? (p.out_nchw != nullptr ? "rsa::conv_ring<3,0,1,HM,f16,3> (Cout 33..48, final store, three fp16 products)" : "rsa::conv_ring<3,0,0,HM,f16,3> (Cout 33..48, three fp16 products)") : "rsa::conv_ring<1,0,0,0,f16,3> (Cout 49..64, three fp16 products)";
     if (ct <= 2 && p.out_nchw != nullptr) return "rsa::conv_ring<2,0,1> (Cout<=32, final store)";

@@ -145,8 +145,17 @@ __device__ __forceinline__ void dma16_v(uint32_t lds_addr, gcptr vaddr) {
 // 0-1 carry tap (2,2) (the other two multiply zero weights); 15 K steps for 48 channels where whole chunks would need 18.  A second
 // kernel rather than a second loop body: two unrolled bodies in one kernel spill hundreds of registers.
 // FMT: enum rsa_plane_fmt of the input planes and weights.  PROD: 3 = hi*hi + lo*hi + hi*lo on split planes, 1 = hi*hi on hi planes.
-template <int SHAPE, int UP, int OUTK, int HM = 0, int FMT = 0, int PROD = 3>
+// XRES 1 (SHAPE 1, one fp16 product, whole chunks: conv5 of a residual dense block, whose residual `x5 * 0.2 + x` is the first 64 channels of
+// its own input): the K loop walks the 32-channel chunks from the LAST to the first, so x's four half chunks are the last fills of a tile;
+// their slots are not handed back until the epilogue has read the residual's hi halves from them (conv_common.h, XL) -- 128 B per pixel that
+// are not fetched from memory a second time.  The loader runs ahead into the other four slots meanwhile.
+template <int SHAPE, int UP, int OUTK, int HM = 0, int FMT = 0, int PROD = 3, int XRES = 0>
 __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(const rsa_conv_params p, const RingAux aux) {
+  static_assert(XRES != 1 || (SHAPE == 1 && PROD == 1 && HM == 0 && UP == 0 && OUTK == 0), "XRES 1: conv5 of a residual dense block only");
+  static_assert(XRES != 2 || (PROD == 1 && FMT == RSA_PF_F16 && OUTK == 0), "XRES 2: one fp16 product, hi-only plane output");
+  constexpr bool XR = XRES == 1;  // (XRES 2: the growth convolutions of a dense block -- hi-only fp16 plane output, LeakyReLU / none, nothing else:
+                                  //  the kernel calls that one epilogue shape directly; without the generic dispatch and its dozen descriptor
+                                  //  tests it keeps 40 fewer lane registers and 140 fewer scalar registers in scratch)
   using R = RingGeoP<PROD>;
   constexpr int STREAMS = SHAPE == 2 ? 2 : 1;
   constexpr int TH = R::TH, TW = R::TW, IH = R::IH, IW = R::IW, PS = R::PS, HALF = R::HALF, SLOT = R::SLOT, NSLOT = R::NSLOT;
@@ -243,7 +252,8 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
           if (any) publish_all();
           ring_wait(&f_free[slot], NCONS * use, f_abort, aux);
         }
-        const int64_t half_unit = tile_unit + (int64_t)(2 * h) * p.in_plane_stride;  // first plane of this half chunk
+        const int hh = XR ? 2 * (nq - 1 - (h >> 1)) + (h & 1) : h;  // XRES: chunks from the last to the first (halves A, B of a chunk stay in order)
+        const int64_t half_unit = tile_unit + (int64_t)(2 * hh) * p.in_plane_stride;  // first plane of this half chunk
         gcptr bh = uniform_ptr((gcptr)p.in_hi + half_unit * 16);
         gcptr bl = uniform_ptr((gcptr)p.in_lo + half_unit * 16);
         const uint32_t dst = __builtin_amdgcn_readfirstlane(ring_lds + (uint32_t)slot * (SLOT * 16));
@@ -267,7 +277,7 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
               iy >>= 1;
               ix >>= 1;
             }
-            const int64_t off = ((int64_t)n * p.in_batch_stride + (int64_t)(2 * h + pl) * p.in_plane_stride + (int64_t)iy * inW + ix) * 16;
+            const int64_t off = ((int64_t)n * p.in_batch_stride + (int64_t)(2 * hh + pl) * p.in_plane_stride + (int64_t)iy * inW + ix) * 16;
             gcptr sh = ok ? (gcptr)p.in_hi + off : (gcptr)&g_zero_unit[0];
             dma16_v(dst + it * 1024, sh);
             if (PROD == 3) {
@@ -357,10 +367,16 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
     }
   }
 
+  // blob K step of the step `koff` steps into unit c of the processing order (koff < 2 * KSU; past the last unit: the next tile's first ones)
+  auto wmap = [&](int c, int koff) -> int {
+    int cc = c + koff / KSU;
+    if (cc >= nq) cc -= nq;
+    return (XR ? nq - 1 - cc : cc) * KSU + koff % KSU;
+  };
   // the first WD K steps' weights (steps wrap around: every tile of the layer reads the same blob)
 #pragma unroll
   for (int d = 0; d < WD; ++d) {
-    load_w(d < nks ? d : 0);
+    load_w(d < nks ? wmap(0, d) : wmap(0, 0));
     if (d + 1 < WD) {  // rotate so that step d sits in wq[d + 1] once all WD are issued
 #pragma unroll
       for (int e = 1; e < WD; ++e)
@@ -373,10 +389,15 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
   uint32_t kc = 0;  // half chunks this stream has consumed: half chunk k lives in slot slot_of(k), which it is the use_of(k)-th to use
   auto slot_of = [&](uint32_t k) -> int { return (STREAMS == 2) ? SPS * g + (int)(k & (SPS - 1)) : (int)(k & (NSLOT - 1)); };
   auto use_of = [&](uint32_t k) -> uint32_t { return k / SPS; };
+  uint32_t xslots = 0;  // XRES: ring slots of x's four half chunks (4 bits each)
   for (int j = (STREAMS == 2 ? g : 0); j < ntw; j += STREAMS) {
     for (int c = 0; c < nq; ++c) {
       const int sA = slot_of(kc), sB = HM ? sA : slot_of(kc + 1);
       const uint32_t needA = use_of(kc) + 1, needB = use_of(kc + 1) + 1;
+      if (XR) {  // x = blob chunks 1 (half chunks 2, 3: unit nq - 2) and 0 (half chunks 0, 1: the last unit)
+        if (c == nq - 2) xslots = (uint32_t)sA << 8 | (uint32_t)sB << 12;
+        if (c == nq - 1) xslots |= (uint32_t)sA | (uint32_t)sB << 4;
+      }
       {
         const int bA = sA * SLOT + lane_u, bB = sB * SLOT + lane_u;
         uA1 = bA + hsel;
@@ -419,12 +440,12 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
         const int ks = i / NPT, sp = i % NPT;
         if (sp == 0) {
           shift_w();
-          const int s = c * KSU + ks + WD;  // the K step WD ahead; past the last one: the first steps of the next tile
-          load_w(s < nks ? s : s - nks);
+          load_w(wmap(c, ks + WD));  // the K step WD ahead; past the last one: the first steps of the next tile
           if (ks == 5) {
             // every read of half A has been consumed by an MFMA (the last ones in the step before): hand the slot back to the loader
+            // (XRES: the slots of x's chunks -- the last two units -- stay until the epilogue has read the residual from them)
             asm volatile("" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(&f_free[sA], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0 && !(XR && c >= nq - 2)) __hip_atomic_fetch_add(&f_free[sA], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -463,7 +484,7 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
 #pragma unroll
         for (int i = FIRST_B; i < NSTEP; ++i) step(i);
         asm volatile("" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(&f_free[sB], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0 && !(XR && c >= nq - 2)) __hip_atomic_fetch_add(&f_free[sB], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         kc += 2;
       }
     }
@@ -471,7 +492,24 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
     {
       int n, ty, tx;
       ring_tile_coords(p.tile_order ? num_tiles - 1 - (tile0 + j * NWG) : tile0 + j * NWG, tiles_x, tiles_y, n, ty, tx);
-      if (!RING_DBG(8)) epilogue<NCT, CTW, NPT, OUTK>(p, acc, n, ty * TH, tx * TW, 0, wct, wpx, li, lg);
+      if (XRES == 2) {
+        if (!RING_DBG(8)) epilogue_impl<NCT, CTW, NPT, 0, AC_LINEAR, 1, RSA_PF_F16>(p, acc, n, ty * TH, tx * TW, 0, wct, wpx, li, lg);
+      } else if (XR) {
+        if (!RING_DBG(8)) {
+          if (p.res2_hi != nullptr)
+            epilogue_impl<NCT, CTW, NPT, 0, AC_LINEAR, 3, RSA_PF_F16, 1>(p, acc, n, ty * TH, tx * TW, 0, wct, wpx, li, lg, s_ring, xslots, SLOT, PS, IW);
+          else
+            epilogue_impl<NCT, CTW, NPT, 0, AC_LINEAR, 2, RSA_PF_F16, 1>(p, acc, n, ty * TH, tx * TW, 0, wct, wpx, li, lg, s_ring, xslots, SLOT, PS, IW);
+        }
+        // the residual's LDS reads have been consumed (their values are in the stores above): hand x's four slots back
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) __hip_atomic_fetch_add(&f_free[(xslots >> (4 * q)) & 15u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      } else if (!RING_DBG(8)) {
+        epilogue<NCT, CTW, NPT, OUTK>(p, acc, n, ty * TH, tx * TW, 0, wct, wpx, li, lg);
+      }
     }
 #pragma unroll
     for (int pt = 0; pt < NPT; ++pt)
@@ -480,7 +518,7 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
   }
 }
 
-template <int SHAPE, int UP, int OUTK, int HM = 0, int FMT = 0, int PROD = 3>
+template <int SHAPE, int UP, int OUTK, int HM = 0, int FMT = 0, int PROD = 3, int XRES = 0>
 static int launch_ring(const rsa_conv_params& p, hipStream_t stream) {
   constexpr int STREAMS = SHAPE == 2 ? 2 : 1;
   using R = RingGeoP<PROD>;
@@ -496,7 +534,7 @@ static int launch_ring(const rsa_conv_params& p, hipStream_t stream) {
   }();
   int gx = cus;  // one persistent workgroup per CU (the ring takes the whole LDS)
   if (gx > num_tiles) gx = (int)num_tiles;
-  hipLaunchKernelGGL((conv_ring<SHAPE, UP, OUTK, HM, FMT, PROD>), dim3((unsigned)gx, 1, 1), dim3((8 + STREAMS) * 64), 0, stream, p, ring_aux());
+  hipLaunchKernelGGL((conv_ring<SHAPE, UP, OUTK, HM, FMT, PROD, XRES>), dim3((unsigned)gx, 1, 1), dim3((8 + STREAMS) * 64), 0, stream, p, ring_aux());
   return (int)hipGetLastError();
 }
 

@@ -251,3 +251,46 @@ def test_conv_ring_reversed_tile_order(device, n, cin, cout, h, w, prod, fmt):
     p.tile_order = 2
     with pytest.raises(RuntimeError):
         ops.run_convs([p], device)
+
+
+@pytest.mark.parametrize('two', [False, True])
+@pytest.mark.parametrize('n,h,w', [(1, 40, 70), (2, 300, 610)])
+def test_conv5_residual_from_the_ring(device, two, n, h, w):
+    """conv5 of a residual dense block under the 'mixed' policy (`x5 * 0.2 + x`, utilities/block.py:454-465 of the reference; every third one also
+    the RRDB's `out * 0.2 + x0`, :340-344): the kernel walks its K loop from the last chunk to the first and reads the hi halves of the
+    residual x from the ring slots that still hold x's planes (conv_ring.h XRES).  Small map, and a map with several tiles per workgroup (the
+    held-back slots rotate through the ring), two images, ragged edges."""
+    cin, cout = 192, 64
+    x = _rand((n, cin, h, w), 31, 1.5)
+    wt = _rand((cout, cin, 3, 3), 32, 1.0 / (cin * 9) ** 0.5)
+    b = _rand((cout,), 33, 0.1)
+    ws = tensors.Planes.empty(n, cin // 8, h, w, device, True, PF_F16, lo_planes=8)
+    src = tensors.nchw_to_planes(x.to(device), True, PF_F16)
+    ws.hi.copy_(src.hi)
+    ws.lo.copy_(src.lo[:, :8])
+    xin = _h(x)  # what the one-product multiply sees
+    xres = tensors.planes_to_nchw(tensors.Planes(src.hi[:, :8].contiguous(), src.lo[:, :8].contiguous()), 64).cpu()  # hi + lo: 22 bits
+    ref = _conv(xin, _h(wt), b) * 0.2 + xres
+    kw = {}
+    if two:
+        r0 = _rand((n, 64, h, w), 34)
+        r0s = tensors.nchw_to_planes(r0.to(device), True, PF_F16)
+        r0p = tensors.Planes.empty(n, cin // 8, h, w, device, True, PF_F16, lo_planes=8)  # another workspace: both residuals share their strides
+        r0p.hi[:, :8].copy_(r0s.hi)
+        r0p.lo.copy_(r0s.lo)
+        ref = ref * 0.2 + tensors.planes_to_nchw(r0s, 64).cpu()
+        kw = dict(res2=(r0p, 0), beta=0.2)
+    wts = ops.ConvWeights.from_oihw(wt, b, 1, device=device, fmt=PF_F16)
+    out = tensors.Planes.empty(n, 8, h, w, device, True, PF_F16)
+    p = ops.conv_params(wts, ws, h, w, cin_planes=cin // 8, res1=(ws, 0), alpha=0.2, out=out, **kw)
+    assert 'XRES' in L.conv_kernel_name(p)
+    outs = []
+    for order in (0, 1):
+        p.tile_order = order
+        ops.run_convs([p], device)
+        torch.cuda.synchronize()
+        assert L.ring_aborts() == 0
+        L.check_status('test')
+        outs.append(tensors.planes_to_nchw(out, 64).cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0] - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
