@@ -116,12 +116,15 @@ __device__ __forceinline__ void w0_load(W0<PROD, CTW>& f, const __amdgpu_buffer_
 // this lane's fragment of cout tile c inside a chunk, or 0xFFFFFFFF (a tile beyond the layer: the range check of the buffer load
 // looks at the vector offset alone and returns zeros).  SWAP: tokens on the MFMA rows (D[token][channel]) instead of the columns.
 // XDB false: the token fragments are single-buffered (32 registers less; their LDS latency is then exposed once per chunk).
-template <int PROD, int CTW, int NPT, bool SWAP, bool XDB = true, int FMT = 0>
+// WAH = K chunks the weight fragments are requested ahead of their multiply.  1: two named buffers (the three-product kernels: a chunk is
+// 24 MFMAs = 384 cycles, about an L2 round trip).  2 (round 3, the one-product kernels: a chunk is 8 MFMAs = 128 cycles, a quarter of one): three
+// buffers, six chunks per loop iteration so that buffer indices stay compile-time constants (weights rotate mod 3, token fragments mod 2).
+template <int PROD, int CTW, int NPT, bool SWAP, bool XDB = true, int FMT = 0, int WAH = 1>
 __device__ __forceinline__ void gemm_tile(f32x4 (&acc)[CTW][NPT], const uint4* lds, int lo0, int nk, const __amdgpu_buffer_rsrc_t rw,
                                           const uint32_t (&woff)[CTW], uint32_t wstep, const W0<PROD, CTW>& w0, int li, int lg) {
   constexpr int NHL = PROD == 3 ? 2 : 1;
   const int bu = lg * SB_TOK + li;
-  bf16x8 w[2][CTW][NHL], bh[XDB ? 2 : 1][NPT], bl[XDB ? 2 : 1][NPT];  // [buffer]: chunk kc lives in buffer kc & 1
+  bf16x8 w[WAH + 1][CTW][NHL], bh[XDB ? 2 : 1][NPT], bl[XDB ? 2 : 1][NPT];  // [buffer]: chunk kc lives in buffer kc % (WAH + 1) / kc & 1
   auto fetch_w = [&](int kc, int b) {
     if (RSA_SB_ABL & 8) return;
 #pragma unroll
@@ -163,6 +166,21 @@ __device__ __forceinline__ void gemm_tile(f32x4 (&acc)[CTW][NPT], const uint4* l
         acc[c][pt] = SWAP ? mfma16<FMT>(bh[xb][pt], w[b][c][0], acc[c][pt]) : mfma16<FMT>(w[b][c][0], bh[xb][pt], acc[c][pt]);
       }
   };
+  auto multiply3 = [&](int wb, int xb_) {  // WAH 2: weights in buffer wb (mod 3), token fragments in buffer xb_ (mod 2)
+    const int xb = XDB ? xb_ : 0;
+    if (RSA_SB_ABL & 4) {
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt) asm volatile("" ::"v"(bh[xb][pt]));
+#pragma unroll
+      for (int c = 0; c < CTW; ++c) asm volatile("" ::"v"(w[wb][c][0]));
+      return;
+    }
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+      for (int c = 0; c < CTW; ++c) acc[c][pt] = SWAP ? mfma16<FMT>(bh[xb][pt], w[wb][c][0], acc[c][pt]) : mfma16<FMT>(w[wb][c][0], bh[xb][pt], acc[c][pt]);
+  };
+  static_assert(WAH == 1 || PROD == 1, "the deeper weight pipeline exists for the one-product kernels");
   if (RSA_SB_ABL & 8) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -184,6 +202,25 @@ __device__ __forceinline__ void gemm_tile(f32x4 (&acc)[CTW][NPT], const uint4* l
 #pragma unroll
     for (int hl = 0; hl < NHL; ++hl) w[0][c][hl] = w0.w[c][hl];
   fetch_x(0, 0);
+  if constexpr (WAH == 2) {
+    // Every fetch is unconditional (an index past the end re-requests the last chunk: at most two wasted requests per multiply), so the
+    // compiler's count of outstanding loads stays exact; the loop is left by a uniform branch behind the last multiply.
+    fetch_w(nk > 1 ? 1 : 0, 1);
+#pragma unroll 1
+    for (int k0 = 0;; k0 += 6) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int k = k0 + i;  // the chunk multiplied in this step (k < nk here)
+        fetch_w(k + 2 < nk ? k + 2 : nk - 1, (i + 2) % 3);
+        if (XDB) fetch_x(k + 1 < nk ? k + 1 : nk - 1, (i + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply3(i % 3, i & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!XDB) fetch_x(k + 1 < nk ? k + 1 : nk - 1, 0);
+        if (k + 1 >= nk) return;
+      }
+    }
+  }
   int kc = 0;
 #pragma unroll 1
   for (; kc + 1 < nk; kc += 2) {

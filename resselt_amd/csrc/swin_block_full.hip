@@ -10,6 +10,12 @@
 // written once: 1.9 KB per token against 5.8 KB for the two half launches (x1 written, read by norm2, read again as the shortcut).
 #include "swin_block.h"
 
+// K chunks of weight prefetch in the one-product kernel (swin_block.h::gemm_tile).  2 was measured on SwinIR-L 1024^2: 142.5 -> 162.4 ms -- the third
+// weight buffer does not fit the 128 registers of the two-windows-per-CU form (83 spilled instead of 43), so the default stays 1.
+#ifndef RSA_SB_WAH1
+#define RSA_SB_WAH1 1
+#endif
+
 namespace rsa {
 
 // PROD 1 (one product, bf16 or fp16 per FMT): no lo images, so the array is 64 KB and TWO windows share a CU -- one window's LayerNorm /
@@ -28,6 +34,7 @@ __global__ __launch_bounds__(512, PROD == 1 ? 4 : 2) void swin_block_kernel(cons
   constexpr int STASH0 = 32 * SB_TOK, STASH1 = 96 * SB_TOK;
   constexpr int RED0 = (PROD == 3 ? 124 : 32) * SB_TOK;
   constexpr int NHL = PROD == 3 ? 2 : 1;
+  constexpr int WAH_ = PROD == 1 ? RSA_SB_WAH1 : 1;  // K chunks of weight prefetch (swin_block.h::gemm_tile)
   __shared__ uint4 s_h[(PROD == 3 ? 2 : 1) * HPL * SB_TOK];  // 128 KB / 64 KB
 
   const int lane = threadIdx.x & 63;
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(512, PROD == 1 ? 4 : 2) void swin_block_kernel(cons
       for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) a[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      gemm_tile<PROD, 4, 4, false, true, FMT>(a, s_h, LO0, nk, rq, woff_qk, qstep, w0qk, li, lg);
+      gemm_tile<PROD, 4, 4, false, true, FMT, WAH_>(a, s_h, LO0, nk, rq, woff_qk, qstep, w0qk, li, lg);
       w0_load<PROD, 2>(w0v, rq, woff_v);
       f32x4 b[4];
 #pragma unroll
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(512, PROD == 1 ? 4 : 2) void swin_block_kernel(cons
         W0<PROD, 2> w0h;
 #pragma unroll
         for (int c = 0; c < 2; ++c) w0h.w[c][0] = w0qk.w[2 * half + c][0];
-        gemm_tile<PROD, 2, 4, false, true, FMT>(a, s_h, LO0, nk, rq, wo, qstep, w0h, li, lg);
+        gemm_tile<PROD, 2, 4, false, true, FMT, WAH_>(a, s_h, LO0, nk, rq, wo, qstep, w0h, li, lg);
         if (half == 1) w0_load<PROD, 2>(w0v, rq, woff_v);
         f32x4 b[2];
 #pragma unroll
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(512, PROD == 1 ? 4 : 2) void swin_block_kernel(cons
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) a[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       // (one product: q and k fragments are live beside this multiply; its token fragments are single-buffered to stay within 128 registers)
-      gemm_tile<PROD, 2, 4, true, PROD == 3, FMT>(a, s_h, LO0, nk, rq, woff_v, qstep, w0v, li, lg);
+      gemm_tile<PROD, 2, 4, true, PROD == 3, FMT, WAH_>(a, s_h, LO0, nk, rq, woff_v, qstep, w0v, li, lg);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         const float bv = p.bqkv[((2 * heads + head) * 2 + dt) * 16 + li];
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(512, PROD == 1 ? 4 : 2) void swin_block_kernel(cons
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int pt = 0; pt < 4; ++pt) a[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    gemm_tile<PROD, 2, 4, false, true, FMT>(a, s_h, LO0, heads, rp, woff_2, (uint32_t)ct_c * NHL * 1024u, w0p, li, lg);
+    gemm_tile<PROD, 2, 4, false, true, FMT, WAH_>(a, s_h, LO0, heads, rp, woff_2, (uint32_t)ct_c * NHL * 1024u, w0p, li, lg);
     w0_load<PROD, 4>(w01, r1, woff_1);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(512, PROD == 1 ? 4 : 2) void swin_block_kernel(cons
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int hl_ = 0; hl_ < NHL; ++hl_) w0h.w[c][hl_] = w01.w[2 * ps + c][hl_];
-    gemm_tile<PROD, 2, 4, false, PROD == 3, FMT>(a1, s_h, LO0, nk, r1, wo, (uint32_t)ct_h * NHL * 1024u, w0h, li, lg);
+    gemm_tile<PROD, 2, 4, false, PROD == 3, FMT, WAH_>(a1, s_h, LO0, nk, r1, wo, (uint32_t)ct_h * NHL * 1024u, w0h, li, lg);
     if (ps == 1) w0_load<PROD, 2>(w02, r2, woff_2);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -421,7 +428,7 @@ __global__ __launch_bounds__(512, PROD == 1 ? 4 : 2) void swin_block_kernel(cons
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int pt = 0; pt < 4; ++pt) a[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    gemm_tile<PROD, 2, 4, false, true, FMT>(a, s_h, LO0, nk2, r2, woff_2, (uint32_t)ct_c * NHL * 1024u, w02, li, lg);
+    gemm_tile<PROD, 2, 4, false, true, FMT, WAH_>(a, s_h, LO0, nk2, r2, woff_2, (uint32_t)ct_c * NHL * 1024u, w02, li, lg);
     f32x4* o_img = (f32x4*)p.out + (int64_t)n * p4 * HW;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
