@@ -63,7 +63,12 @@ class SPAN(EngineModule):
         fc, pf, s = self.fc, self.fc // 8, self.upscale
         with_lo = products == 3
         wide = with_lo or products.name == 'mixed'  # buffers read by a three-product layer (conv_cat, the head) keep hi + lo
-        x_pl = plan.planes(n, (c + 7) // 8, h, w, wide)
+        ring_first = W['conv_1'].cin_planes == 2  # a second, all-zero input plane: the first convolution takes the ring schedule (see SpanPlus)
+        x_pl = plan.planes(n, 2 if ring_first else (c + 7) // 8, h, w, wide)
+        if ring_first:
+            x_pl.hi.zero_()
+            if x_pl.lo is not None:
+                x_pl.lo.zero_()
         chain = SpabChain(plan, W, n, h, w, fc, L.ACT_SILU, with_lo, cat_lo=wide)
         mean = W['mean'] if self.is_norm else None
         scale = self.img_range if self.is_norm else 1.0
@@ -73,7 +78,7 @@ class SPAN(EngineModule):
             ops.nchw_to_planes(x, x_pl, mean, scale)
 
         cat = chain.new_cat()
-        xf = plan.f32map(n, fc, h, w)
+        xf = None if chain.plane_shortcut else plan.f32map(n, fc, h, w)  # (the gate's shortcut as an f32 map: plain-bf16 mode only)
         feat = plan.planes(n, pf, h, w, wide)
         plan.conv(ops.conv_params(W['conv_1'], x_pl, h, w, out=cat, out_plane_off=0, out_f32=xf))
         names = dict(first='block_1', middle=[f'block_{i}' for i in range(2, 6)], end='block_6', conv_2='conv_2', conv_cat='conv_cat')

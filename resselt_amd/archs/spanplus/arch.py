@@ -131,7 +131,15 @@ class SpanPlus(EngineModule):
         fc, pf, s = self.fc, self.fc // 8, self.upscale
         with_lo = products == 3
         wide = with_lo or products.name == 'mixed'  # buffers read by a three-product layer (conv_cat, the head) keep hi + lo
-        x_pl = plan.planes(n, (c + 7) // 8, h, w, wide)
+        # The first convolution (3 -> fc) takes the ring schedule when its input has a whole half chunk of 16 channels: a second, all-zero plane
+        # (zeroed once, here) beside the image's plane, weights padded to match (`_pack`).  The chunk-barrier kernel ran it at 0.36 ms per
+        # 2 Mpx (one fill in flight per CU); fp16 three-product form only (the ring's half mode in three products exists for fp16 planes).
+        ring_first = W['feats.0'].cin_planes == 2
+        x_pl = plan.planes(n, 2 if ring_first else (c + 7) // 8, h, w, wide)
+        if ring_first:
+            x_pl.hi.zero_()
+            if x_pl.lo is not None:
+                x_pl.lo.zero_()
         chain = SpabChain(plan, W, n, h, w, fc, L.ACT_MISH, with_lo, cat_lo=wide)
         preproj = self.upsampler_kind == 'dys' and 'upsampler.zproj' in W
         need_f32_feat = self.upsampler_kind == 'dys' and not preproj
@@ -143,7 +151,8 @@ class SpanPlus(EngineModule):
         nb = len(self.blocks)
         feat = plan.planes(n, pf, h, w, wide)
         feat_f32 = plan.f32map(n, fc, h, w) if need_f32_feat else None
-        xf = [plan.f32map(n, fc, h, w) for _ in range(2)]
+        # (the f32 copies of a SPABS input exist only where the gate's shortcut is read from an f32 map: plain-bf16 mode)
+        xf = [None if chain.plane_shortcut else plan.f32map(n, fc, h, w) for _ in range(2)]
         if nb == 0:
             plan.conv(ops.conv_params(W['feats.0'], x_pl, h, w, out=feat, out_f32=feat_f32))
         else:
