@@ -307,7 +307,7 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
   };
   // EM 2 (plane residuals of a residual dense block's conv5): the residual halves are fetched PD steps ahead in raw form.  One step
   // ahead left every one of the 8 steps of a tile waiting for a full memory latency (the one-product multiply of a tile is as long as
-  // those eight waits: profiles/r03_b); PD steps in flight cost (PD + 1) * 8 (16 with a second residual) registers, free after the K loop.
+  // those eight waits); PD steps in flight cost (PD + 1) * 8 (16 with a second residual) registers, free after the K loop.
 #ifndef RSA_EPI_PD
 #define RSA_EPI_PD 3
 #endif

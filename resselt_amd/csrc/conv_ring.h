@@ -67,10 +67,13 @@ typedef const __attribute__((address_space(1))) char* gcptr;
 #define RSA_RING_INFL1 2  // fills left in flight behind the one being published
 #endif
 #ifndef RSA_RING_WD1
-#define RSA_RING_WD1 3  // K steps of weight prefetch (2 -> 3: -1.7 % on the RRDBNet frame, profiles/r03_b)
+#define RSA_RING_WD1 3  // K steps of weight prefetch (RRDBNet frame: 2 steps 94.05 ms, 3 steps 93.2 ms, 4 steps 92.85 ms: profiles/r03_q_*)
+#endif
+#ifndef RSA_RING_WDX
+#define RSA_RING_WDX 4  // ... of the two RRDBNet kernels that call their epilogue directly (XRES 1 / 2): they have the registers for a fourth step
 #endif
 #ifndef RSA_RING_DEPTH1
-#define RSA_RING_DEPTH1 4  // pixel-tile steps of LDS fragment prefetch
+#define RSA_RING_DEPTH1 4  // pixel-tile steps of LDS fragment prefetch (3, 4, 5: +-0.1 %, profiles/r03_q_*)
 #endif
 
 template <int PROD>
@@ -311,7 +314,7 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
 
   // weights: per (chunk, K step 0..8, cout tile, hi|lo) one 1 KiB A fragment, streamed from L2 WD K steps ahead
   constexpr int KSU = HM ? 5 : 9;  // K steps per unit
-  constexpr int WD = PROD == 3 ? 1 : RSA_RING_WD1;  // K steps of weight prefetch (a one-product K step is 16 MFMAs = 256 cycles: less than an L2 hit under load)
+  constexpr int WD = PROD == 3 ? 1 : (XRES ? RSA_RING_WDX : RSA_RING_WD1);  // K steps of weight prefetch (a one-product K step is 16 MFMAs = 256 cycles: less than an L2 hit under load)
   const int nks = nq * KSU;
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_packed, 0, (uint32_t)((int64_t)nks * ct_total * NHL * 64 * 16), 0x00020000);
   uint32_t woff[CTW];
