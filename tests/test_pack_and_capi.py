@@ -188,3 +188,19 @@ def test_upphase_layout_is_the_upsampled_convolution():
         hi = _bf16(torch.tensor(float(want)))
         assert blob[phase, half, s, ct, 0, lane, j].item() == hi.item()
         assert blob[phase, half, s, ct, 1, lane, j].item() == _bf16(torch.tensor(float(want)) - hi.float()).item()
+
+
+def test_plan_alternates_the_tile_order_of_consecutive_layers():
+    """Serpentine layer order: every other convolution of a plan carries ``tile_order = 1``; a builder can switch it off."""
+    from resselt_amd.engine import base
+
+    plan = base.Plan('cpu')
+    orders = []
+    for _ in range(5):
+        p = L.ConvParams()
+        p.batch, p.H, p.W, p.cin_planes, p.cout, p.products = 1, 16, 32, 8, 32, 1
+        orders.append(plan.conv(p).tile_order)
+    assert orders == ([0, 1, 0, 1, 0] if base._SERPENTINE else [0] * 5)
+    plan2 = base.Plan('cpu')
+    plan2.serpentine = False
+    assert [plan2.conv(L.ConvParams()).tile_order for _ in range(3)] == [0, 0, 0]
