@@ -69,8 +69,9 @@ __device__ __forceinline__ float act_apply(float v, int act, float prm) {
   } else if (AC == AC_MISH) {
     // torch: x * tanh(softplus(x)) with softplus threshold 20.  tanh(ln(1+n)) = (n^2+2n)/(n^2+2n+2) for n = e^x, so one exp and
     // one reciprocal replace log1p + tanh (exact algebra)
-    if (v > 20.f) return v;  // tanh(x) == 1.0f in f32 from x = 9.02 on
-    const float n = exp_fast(v);
+    // (softplus' threshold: from v = 20 on n(n + 2) = 2.4e17 and the ratio below is 1.0f, so clamping the exponent gives torch's `x` branch
+    //  without a compare and a select per value; it also keeps e^v finite)
+    const float n = exp_fast(fminf(v, 20.f));
     const float t = n * (n + 2.f);
     return v * (t * __builtin_amdgcn_rcpf(t + 2.f));
   } else if (AC == AC_SILU) {
@@ -438,7 +439,8 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[e][r] = v[e][r] * p.beta + rr[r];
           }
-          if (G) {  // (the specialised shapes have whole cout tiles)
+          if (G && (p.cout & 15)) {  // channels beyond Cout -> zeros.  A wave-uniform test first: layers whose Cout fills its tiles (32, 48, 64 ...:
+                                     // every hot layer) skip the compare + select per value -- as expensive as a tenth of a Mish
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               if (c0 + r >= p.cout) v[e][r] = 0.f;
