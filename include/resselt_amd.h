@@ -350,6 +350,9 @@ typedef struct rsa_swin_mlp_block_params {
   void* out_lo;
   int64_t out_plane_stride; /* 16-byte units */
   int64_t out_batch_stride;
+  int32_t fmt;             /* enum rsa_plane_fmt of w1 / w2 and of the kernel's internal images (selects the matrix instruction): RSA_PF_F16 with
+                              products == 1 is the one-product fp16 form; out_hi / out_lo are bf16 planes in every form */
+  int32_t reserved0;       /* must be 0 */
 } rsa_swin_mlp_block_params;
 
 int rsa_swin_mlp_block(const rsa_swin_mlp_block_params* p, void* stream);

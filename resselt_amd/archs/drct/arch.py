@@ -23,8 +23,8 @@ import torch
 
 from ...engine import lib as L
 from ...engine import ops
-from ...engine.tensors import Planes
-from ...engine.base import EngineModule, Plan
+from ...engine.tensors import PF_BF16, PF_F16, Planes
+from ...engine.base import EngineModule, Plan, check_fp16_range
 from ...engine.paramtree import build_param_tree
 from ..dat.arch import bias_fragments
 from ..swinir.arch import relative_position_index, shift_attn_mask
@@ -119,6 +119,21 @@ def drct_param_shapes(in_chans, embed_dim, num_layers, num_heads, window, mlp_ra
 
 class DRCT(EngineModule):
     hyperparameters = {}
+    # 'mixed' (what 'auto' selects): the Linear layers fed by a LayerNorm or by another Linear layer -- qkv, fc1, fc2 and the 1x1 `adjust`
+    # convolutions, 85 % of the multiply-accumulates, every one of them feeding the f32 token stream through the next LayerNorm -- run ONE
+    # fp16 product on hi planes (LayerNorm outputs, hidden activations and block outputs are written as fp16 hi planes: 2 bytes per channel
+    # instead of 4).  The attention kernel reads and writes bf16 split planes, so qkv's output and proj stay in the three-product format; the
+    # 3x3 convolutions (conv_first, conv_after_body, the reconstruction head) run three bf16 products as in RRDBNet's tail.
+    auto_precision = 'mixed'
+    precisions = ('bf16x3', 'bf16', 'mixed')
+    precision_table = {'mixed': (3, PF_BF16)}
+
+    @staticmethod
+    def layer_policy(name: str) -> tuple[int, int]:
+        """(products, plane format of inputs and weights) of layer ``name`` under 'mixed'."""
+        if name.endswith(('.attn.qkv', '.mlp.fc1', '.mlp.fc2')) or '.adjust' in name:
+            return 1, PF_F16
+        return 3, PF_BF16
 
     def __init__(self, *, img_size=64, patch_size=1, in_chans=3, embed_dim=180, depths=(6, 6, 6, 6, 6, 6), num_heads=(6, 6, 6, 6, 6, 6),
                  window_size=16, mlp_ratio=2.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1,
@@ -156,13 +171,20 @@ class DRCT(EngineModule):
         sd = {k: v.detach().to(device) for k, v in self.state_dict().items()}
         W: dict = {}
 
+        mixed = products.name == 'mixed'
+
+        def policy(name):
+            return self.layer_policy(name) if mixed else (int(products), products.fmt)
+
         def conv(name):
-            W[name] = ops.ConvWeights.from_oihw(sd[f'{name}.weight'], sd.get(f'{name}.bias'), products, device=device)
+            prod, fmt = policy(name)
+            W[name] = ops.ConvWeights.from_oihw(sd[f'{name}.weight'], sd.get(f'{name}.bias'), prod, device=device, fmt=fmt)
 
         def lin(name, w=None, b=None, cin_planes=None):
             w = sd[f'{name}.weight'] if w is None else w
             b = sd.get(f'{name}.bias') if b is None else b
-            W[name] = ops.ConvWeights.from_oihw(w[:, :, None, None], b, products, cin_planes=cin_planes, device=device)
+            prod, fmt = policy(name)
+            W[name] = ops.ConvWeights.from_oihw(w[:, :, None, None], b, prod, cin_planes=cin_planes, device=device, fmt=fmt)
 
         def ln(name):
             W[name] = (sd[f'{name}.weight'].float().contiguous(), sd[f'{name}.bias'].float().contiguous())
@@ -189,10 +211,11 @@ class DRCT(EngineModule):
         ln('norm')
         if self.resi == 'identity':  # nn.Identity as a 1x1 convolution (see _build_plan)
             eye = torch.eye(self.embed_dim, dtype=torch.float32, device=device)[:, :, None, None]
-            W['identity'] = ops.ConvWeights.from_oihw(eye, torch.zeros(self.embed_dim, dtype=torch.float32, device=device), products, device=device)
+            W['identity'] = ops.ConvWeights.from_oihw(eye, torch.zeros(self.embed_dim, dtype=torch.float32, device=device), int(products), device=device, fmt=products.fmt)
         for name in ('conv_after_body', 'conv_before_upsample.0', 'upsample.0', 'upsample.2', 'upsample.4', 'conv_last'):
             if f'{name}.weight' in sd:
                 conv(name)
+        check_fp16_range(W.values())
         W['mean'] = torch.tensor(RGB_MEAN if self.in_chans == 3 else [0.0] * self.in_chans, dtype=torch.float32, device=device)
         return W
 
@@ -248,11 +271,16 @@ class DRCT(EngineModule):
         cat = [plan.f32map(n, wide, H, Wd) for _ in range(2)]  # dense concatenation of a group: x | x1 | x2 | x3 | x4
         blk = [plan.f32map(n, wide, H, Wd) for _ in range(2)]  # a Swin block's two residual sums
         max_pad = max(heads * 32 * -(-(dim // heads) // 32) for nh in self.num_heads for dim, heads, _, _ in block_dims(C_, gc, nh))
-        a_pl = plan.planes(n, (wide + 7) // 8, H, Wd, with_lo)
+        mixed = products.name == 'mixed'
+        # 'mixed': what a one-product Linear layer reads is an fp16 hi plane (2 bytes per channel); what the attention kernel and the 3x3
+        # convolutions read stays bf16 hi + lo
+        one = dict(with_lo=False, fmt=PF_F16) if mixed else dict(with_lo=with_lo)
+        a_pl = plan.planes(n, (wide + 7) // 8, H, Wd, **one)  # LayerNorm outputs -> qkv / fc1
+        n_pl = plan.planes(n, (C_ + 7) // 8, H, Wd, with_lo) if mixed else a_pl  # the last LayerNorm -> conv_after_body (three products)
         qkv_pl = plan.planes(n, 3 * max_pad // 8, H, Wd, with_lo)
         o_pl = plan.planes(n, max_pad // 8, H, Wd, with_lo)
-        hid_pl = plan.planes(n, (int(wide * max(self.mlp_ratio, 1.0)) + 7) // 8, H, Wd, with_lo)
-        t_pl = plan.planes(n, (wide + 7) // 8, H, Wd, with_lo)  # a block's output as planes (input of its adjust convolution)
+        hid_pl = plan.planes(n, (int(wide * max(self.mlp_ratio, 1.0)) + 7) // 8, H, Wd, **one)
+        t_pl = plan.planes(n, (wide + 7) // 8, H, Wd, **one)  # a block's output as planes (input of its adjust convolution)
         body_pl = plan.planes(n, (C_ + 7) // 8, H, Wd, with_lo)
         y0_pl = plan.planes(n, 8, H, Wd, with_lo)
         # the pixel-shuffle stages of the head: a plain tensor the final store writes, re-laid out as planes for the next convolution
@@ -280,6 +308,7 @@ class DRCT(EngineModule):
             if out_planes is not None:
                 lp.out_hi, lp.out_lo = out_planes.hi_ptr(), out_planes.lo_ptr()
                 lp.out_plane_stride, lp.out_batch_stride = out_planes.plane_stride, out_planes.batch_stride
+                lp.out_fmt = out_planes.fmt
             lp.out_f32 = None if out_f32 is None else out_f32.data_ptr()
             plan.call(lambda: L.check(lib.rsa_layernorm(C.byref(lp), C.c_void_p(ops.current_stream_ptr(dev))), 'rsa_layernorm'))
             plan.count_launches(1)
@@ -289,7 +318,7 @@ class DRCT(EngineModule):
             ap.batch, ap.H, ap.W, ap.Hp, ap.Wp = n, H, Wd, H, Wd
             ap.win_h = ap.win_w = win
             ap.shift_h = ap.shift_w = win // 2 if shifted else 0
-            ap.heads, ap.head0, ap.heads_total, ap.products, ap.head_chunks = heads, 0, heads, products, chunks
+            ap.heads, ap.head0, ap.heads_total, ap.products, ap.head_chunks = heads, 0, heads, int(products), chunks
             ap.qkv_hi, ap.qkv_lo, ap.qkv_plane_stride, ap.qkv_batch_stride = qkv_pl.hi_ptr(), qkv_pl.lo_ptr(), qkv_pl.plane_stride, qkv_pl.batch_stride
             ap.bias_frag = W[f'{name}.bias_frag'].data_ptr()
             ap.out_hi, ap.out_lo, ap.out_plane_stride, ap.out_batch_stride = o_pl.hi_ptr(), o_pl.lo_ptr(), o_pl.plane_stride, o_pl.batch_stride
@@ -339,11 +368,11 @@ class DRCT(EngineModule):
                         plan.conv(f32_view_conv(W[f'layers.{i}.adjust{j}'], t_pl, cin_planes=cp, res1=chan_view(cur, 0, C_), alpha=0.2, out_f32=chan_view(nxt, 0, C_)))
                 ci ^= 1
             cur = cat[ci]
-            layernorm('norm', chan_view(cur, 0, C_), C_, out_planes=a_pl)
+            layernorm('norm', chan_view(cur, 0, C_), C_, out_planes=n_pl)
             cp0 = (C_ + 7) // 8
             # conv_after_body(forward_features(x)) + conv_first(x) (arch.py:781): a 3x3 convolution, or nn.Identity (arch.py:731-732) -- the
             # latter as a 1x1 convolution with the identity matrix, whose epilogue adds conv_first's map and writes the planes the head reads
-            plan.conv(ops.conv_params(W['conv_after_body' if self.resi == '1conv' else 'identity'], a_pl, H, Wd, cin_planes=cp0, res1=first, alpha=1.0, out=body_pl))
+            plan.conv(ops.conv_params(W['conv_after_body' if self.resi == '1conv' else 'identity'], n_pl, H, Wd, cin_planes=cp0, res1=first, alpha=1.0, out=body_pl))
             plan.conv(ops.conv_params(W['conv_before_upsample.0'], body_pl, H, Wd, cin_planes=cp0, act=L.ACT_LRELU, act_param=0.01, out=y0_pl))
             y, hh, ww = y0_pl, H, Wd
             for name, r, shuffled, ny in stages:

@@ -22,7 +22,8 @@ import torch
 
 from ...engine import lib as L
 from ...engine import ops, swinblocks
-from ...engine.base import EngineModule, Plan
+from ...engine.base import EngineModule, Plan, check_fp16_range
+from ...engine.tensors import PF_BF16, PF_F16
 from ...engine.paramtree import build_param_tree
 from ..dat.arch import attn_tiles
 from ..swinir.arch import HEAD_PAD, regroup_proj, regroup_qkv
@@ -131,6 +132,23 @@ def hat_param_shapes(in_chans, embed_dim, depths, num_heads, window, compress_ra
 
 class HAT(EngineModule):
     hyperparameters = {}
+    # 'mixed' (what 'auto' selects when the MLP halves run the fused kernel): the layers fed by a LayerNorm -- qkv, the CAB's two 3x3
+    # convolutions and the fused norm2 + fc1 + GELU + fc2 half -- run ONE fp16 product on hi planes; the attention kernel reads and writes
+    # bf16 split planes, so qkv's output and proj keep the three-product format, as do the group / head convolutions.
+    precisions = ('bf16x3', 'bf16', 'mixed')
+    precision_table = {'mixed': (3, PF_BF16)}
+
+    @property
+    def auto_precision(self) -> str:
+        return 'mixed' if self.fused_mlp and swinblocks.mlp_block_fits(self.embed_dim, int(self.embed_dim * self.mlp_ratio)) else 'bf16x3'
+
+    @staticmethod
+    def layer_policy(name: str) -> tuple[int, int]:
+        """(products, plane format of inputs and weights) of layer ``name`` under 'mixed'."""
+        if name.endswith(('.qkv', '.mlp.fc1', '.mlp.fc2')) or '.conv_block.cab.' in name:
+            return 1, PF_F16
+        return 3, PF_BF16
+
     fused_mlp = True  # LayerNorm + fc1 + GELU + fc2 + shortcut as one launch where the widths allow it (engine/swinblocks.py)
 
     def __init__(self, *, img_size=64, patch_size=1, in_chans=3, embed_dim=96, depths=(6, 6, 6, 6), num_heads=(6, 6, 6, 6), window_size=7,
@@ -166,13 +184,20 @@ class HAT(EngineModule):
         def f32(t):
             return t.to(torch.float32).contiguous()
 
+        mixed = products.name == 'mixed'
+
+        def policy(name):
+            return self.layer_policy(name) if mixed else (int(products), products.fmt)
+
         def conv(name):
-            W[name] = ops.ConvWeights.from_oihw(sd[f'{name}.weight'], sd.get(f'{name}.bias'), products, device=device)
+            prod, fmt = policy(name)
+            W[name] = ops.ConvWeights.from_oihw(sd[f'{name}.weight'], sd.get(f'{name}.bias'), prod, device=device, fmt=fmt)
 
         def lin(name, w=None, b=None, cin_planes=None):
             w = sd[f'{name}.weight'] if w is None else w
             b = sd.get(f'{name}.bias') if b is None else b
-            W[name] = ops.ConvWeights.from_oihw(w[:, :, None, None], b, products, cin_planes=cin_planes, device=device)
+            prod, fmt = policy(name)
+            W[name] = ops.ConvWeights.from_oihw(w[:, :, None, None], b, prod, cin_planes=cin_planes, device=device, fmt=fmt)
 
         def ln(name):
             W[name] = (f32(sd[f'{name}.weight']), f32(sd[f'{name}.bias']))
@@ -228,10 +253,11 @@ class HAT(EngineModule):
         if self.resi == '1conv':
             conv('conv_after_body')
         else:  # 'identity': the residual adds still run as (exact) identity k1 launches
-            W['identity'] = ops.ConvWeights.from_oihw(torch.eye(C_, device=device)[:, :, None, None], None, products, device=device)
+            W['identity'] = ops.ConvWeights.from_oihw(torch.eye(C_, device=device)[:, :, None, None], None, int(products), device=device, fmt=products.fmt)
         for name in ('conv_before_upsample.0', 'conv_last', 'upsample.0', 'upsample.2', 'upsample.4'):
             if f'{name}.weight' in sd:
                 conv(name)
+        check_fp16_range(W.values())
         W['mean'] = torch.tensor(RGB_MEAN if self.in_chans == 3 else [0.0] * self.in_chans, dtype=torch.float32, device=device)
         return W
 
@@ -290,13 +316,18 @@ class HAT(EngineModule):
 
         first = plan.f32map(n, C_, H, Wd)
         pool = [plan.f32map(n, C_, H, Wd) for _ in range(5)]
-        a_pl = plan.planes(n, cp, H, Wd, with_lo)
+        mixed = products.name == 'mixed'
+        one = dict(with_lo=False, fmt=PF_F16) if mixed else dict(with_lo=with_lo)  # what a one-product layer reads: an fp16 hi plane
+        a_pl = plan.planes(n, cp, H, Wd, **one)  # norm1 -> qkv and the CAB
+        n_pl = plan.planes(n, cp, H, Wd, with_lo) if mixed else a_pl  # the last LayerNorm -> conv_after_body (three products)
         qkv_pl = plan.planes(n, 3 * max_heads * HEAD_PAD // 8, H, Wd, with_lo)
         o_pl = plan.planes(n, max_heads * HEAD_PAD // 8, H, Wd, with_lo)
         fuse_mlp = self.fused_mlp and swinblocks.mlp_block_fits(C_, hidden)
+        if mixed and not fuse_mlp:
+            raise NotImplementedError("HAT 'mixed' needs the fused MLP half (C <= 256, hidden <= 512); use precision 'bf16x3'")
         hid_pl = None if fuse_mlp else plan.planes(n, (hidden + 7) // 8, H, Wd, with_lo)
         body_pl = plan.planes(n, cp, H, Wd, with_lo)
-        cab_a = plan.planes(n, (self.compress + 7) // 8, H, Wd, with_lo)
+        cab_a = plan.planes(n, (self.compress + 7) // 8, H, Wd, **one)
         cab_b = plan.planes(n, cp, H, Wd, with_lo)
         gate = torch.empty((n, cp * 8), dtype=torch.float32, device=dev)
         ws_gate = torch.empty((max(int(lib.rsa_channel_gate_workspace_bytes(n, H, Wd, cp)), 16) // 4,), dtype=torch.float32, device=dev)
@@ -310,6 +341,7 @@ class HAT(EngineModule):
             if out_planes is not None:
                 lp.out_hi, lp.out_lo = out_planes.hi_ptr(), out_planes.lo_ptr()
                 lp.out_plane_stride, lp.out_batch_stride = out_planes.plane_stride, out_planes.batch_stride
+                lp.out_fmt = out_planes.fmt
             lp.out_f32 = None if out_f32 is None else out_f32.data_ptr()
             launch('rsa_layernorm', lp)
 
@@ -317,7 +349,7 @@ class HAT(EngineModule):
             ap = L.RectAttnParams()
             ap.batch, ap.H, ap.W, ap.Hp, ap.Wp = n, H, Wd, H, Wd
             ap.win_h, ap.win_w, ap.shift_h, ap.shift_w = ws, ws, shift, shift
-            ap.heads, ap.head0, ap.heads_total, ap.products = heads, 0, heads, products
+            ap.heads, ap.head0, ap.heads_total, ap.products = heads, 0, heads, int(products)
             ap.qkv_hi, ap.qkv_lo = qkv_pl.hi_ptr(), qkv_pl.lo_ptr()
             ap.qkv_plane_stride, ap.qkv_batch_stride = qkv_pl.plane_stride, qkv_pl.batch_stride
             ap.bias_frag = W[f'{name}.bias_frag'].data_ptr()
@@ -406,9 +438,9 @@ class HAT(EngineModule):
                 free.append(rg_in)
             free.append(cur)
             cur = out
-        layernorm('norm', cur, out_planes=a_pl)
+        layernorm('norm', cur, out_planes=n_pl)
         tail = W['conv_after_body'] if self.resi == '1conv' else W['identity']
-        plan.conv(ops.conv_params(tail, a_pl, H, Wd, cin_planes=cp, res1=first, alpha=1.0, out=body_pl))  # + conv_first output (arch.py:1104)
+        plan.conv(ops.conv_params(tail, n_pl, H, Wd, cin_planes=cp, res1=first, alpha=1.0, out=body_pl))  # + conv_first output (arch.py:1104)
 
         out_shape = (n, self.in_chans, H * s, Wd * s)
         out_buf = {'y': torch.empty(out_shape, dtype=dtype, device=dev)}

@@ -21,7 +21,9 @@ __device__ uint4 g_zero_unit_gk[4];  // source of zero units for lanes past the 
 constexpr int GK_WAVES = 8;
 
 // TP = pixels per tile (64, or 32 when the whole-K image of 64 pixels would not fit twice in LDS)
-template <int PROD, int CTW, int NQ, int GK_TP>
+// FMT: plane format of the input planes and weights (selects the matrix instruction); the outputs follow p.out_fmt.  Round 3: one fp16
+// product on hi planes (PROD 1, FMT RSA_PF_F16) -- the Linear layers of DRCT / HAT / DAT under their 'mixed' precision policies.
+template <int PROD, int CTW, int NQ, int GK_TP, int FMT = 0>
 __global__ __launch_bounds__(GK_WAVES * 64, 2) void gemm_k1_kernel(const rsa_conv_params p) {
   constexpr int NHL = (PROD == 3) ? 2 : 1;
   constexpr int NPT = GK_TP / 16;
@@ -140,12 +142,12 @@ __global__ __launch_bounds__(GK_WAVES * 64, 2) void gemm_k1_kernel(const rsa_con
             if (PROD == 3) {
               const bf16x8 bl = *(const bf16x8*)&sx[((NQ + q) * 4) * GK_TP + bunit + pt * 16];
 #pragma unroll
-              for (int c = 0; c < CTW; ++c) acc[pt][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[c][q][1], bh, acc[pt][c], 0, 0, 0);
+              for (int c = 0; c < CTW; ++c) acc[pt][c] = mfma16<FMT>(wr[c][q][1], bh, acc[pt][c]);
 #pragma unroll
-              for (int c = 0; c < CTW; ++c) acc[pt][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[c][q][0], bl, acc[pt][c], 0, 0, 0);
+              for (int c = 0; c < CTW; ++c) acc[pt][c] = mfma16<FMT>(wr[c][q][0], bl, acc[pt][c]);
             }
 #pragma unroll
-            for (int c = 0; c < CTW; ++c) acc[pt][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[c][q][0], bh, acc[pt][c], 0, 0, 0);
+            for (int c = 0; c < CTW; ++c) acc[pt][c] = mfma16<FMT>(wr[c][q][0], bh, acc[pt][c]);
           }
         }
       }
@@ -237,8 +239,8 @@ __global__ __launch_bounds__(GK_WAVES * 64, 2) void gemm_k1_kernel(const rsa_con
               uint32_t h[2][2], l[2][2];
 #pragma unroll
               for (int e = 0; e < 2; ++e) {
-                split2(v[e][0], v[e][1], h[e][0], l[e][0]);
-                split2(v[e][2], v[e][3], h[e][1], l[e][1]);
+                split2_rt(p.out_fmt == RSA_PF_F16, v[e][0], v[e][1], h[e][0], l[e][0]);
+                split2_rt(p.out_fmt == RSA_PF_F16, v[e][2], v[e][3], h[e][1], l[e][1]);
               }
               typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
               const u32x2 h0 = __builtin_amdgcn_permlane16_swap(h[0][0], h[1][0], false, false);
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(GK_WAVES * 64, 2) void gemm_k1_kernel(const rsa_con
   }
 }
 
-template <int PROD, int CTW, int NQ, int GK_TP>
+template <int PROD, int CTW, int NQ, int GK_TP, int FMT = 0>
 static int launch_gemm(const rsa_conv_params& p, hipStream_t stream) {
   const int64_t HW = (int64_t)p.H * p.W;
   const int64_t num_tiles = ((HW + GK_TP - 1) / GK_TP) * p.batch;
@@ -273,21 +275,21 @@ static int launch_gemm(const rsa_conv_params& p, hipStream_t stream) {
   if (resident == 0) {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_k1_kernel<PROD, CTW, NQ, GK_TP>, GK_WAVES * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_k1_kernel<PROD, CTW, NQ, GK_TP, FMT>, GK_WAVES * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipGetLastError();
     resident = per_cu * prop.multiProcessorCount;
     resident_cache.store(resident, std::memory_order_relaxed);
   }
   int gx = resident;
   if (gx > num_tiles) gx = (int)num_tiles;
-  hipLaunchKernelGGL((gemm_k1_kernel<PROD, CTW, NQ, GK_TP>), dim3((unsigned)gx), dim3(GK_WAVES * 64), 0, stream, p);
+  hipLaunchKernelGGL((gemm_k1_kernel<PROD, CTW, NQ, GK_TP, FMT>), dim3((unsigned)gx), dim3(GK_WAVES * 64), 0, stream, p);
   return (int)hipGetLastError();
 }
 
 // Returns -100 when the layer is not a fit for this schedule (caller falls back to the halo-tile kernels).
 int gemm_k1_launch(const rsa_conv_params& p, hipStream_t stream) {
   if (p.ksize != 1 || p.out_nchw != nullptr || p.upsample2x) return -100;
-  if (p.in_fmt != RSA_PF_BF16 || p.out_fmt != RSA_PF_BF16) return -100;  // bf16 planes only (fp16 layers take conv_kernel<1, ...>)
+  if (p.in_fmt == RSA_PF_F16 && p.products != 1) return -100;  // fp16 planes: the one-product form only (three fp16 products take conv_kernel<1, ...>)
   if (p.res1_hi != nullptr || p.res2_hi != nullptr) return -100;  // plane residuals: only the halo-tile kernels' epilogue reads them
   if (p.act == RSA_ACT_MISH || p.act == RSA_ACT_SILU) return -100;  // only the linear class, GELU and the SPAB gate are compiled into this schedule
   if (p.cout < 96) return -100;  // too few cout tiles to occupy 8 waves
@@ -296,7 +298,7 @@ int gemm_k1_launch(const rsa_conv_params& p, hipStream_t stream) {
     if (nq <= 8) return launch_gemm<3, 2, 8, 64>(p, stream);
     if (nq <= 16) return launch_gemm<3, 1, 16, 32>(p, stream);
   } else {
-    if (nq <= 16) return launch_gemm<1, 2, 16, 64>(p, stream);
+    if (nq <= 16) return p.in_fmt == RSA_PF_F16 ? launch_gemm<1, 2, 16, 64, RSA_PF_F16>(p, stream) : launch_gemm<1, 2, 16, 64>(p, stream);
   }
   return -100;
 }

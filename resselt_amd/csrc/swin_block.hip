@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn_block_kernel(const rsa_swin_
 // ------------------------------------------------------------------------------------------------ MLP half
 // One workgroup (8 waves) = 64 consecutive tokens of one image.  (The hidden image takes 120 KB of LDS at 480 channels: one
 // workgroup per CU.)
-template <int PROD>
+template <int PROD, int FMT = 0>
 __global__ __launch_bounds__(512) void swin_mlp_block_kernel(const rsa_swin_mlp_block_params p) {
   constexpr int HPL = 64;  // planes of the LDS image (512 hidden channels)
   constexpr int LO0 = HPL * SB_TOK;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(512) void swin_mlp_block_kernel(const rsa_swin_mlp_
         res[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (pix >= 0 && g < p4 && !(RSA_SB_ABL & (16 | 256))) res[c][pt] = x_img[MAPIDX(g, pix)];
       }
-    ln_store<PROD>(row, s_h, LO0, 4 * nk1, p.C, p.gamma, p.beta, p.eps, t, token_pix(t), lane);
+    ln_store<PROD, FMT>(row, s_h, LO0, 4 * nk1, p.C, p.gamma, p.beta, p.eps, t, token_pix(t), lane);
   }
   __syncthreads();
 
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512) void swin_mlp_block_kernel(const rsa_swin_mlp_
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int pt = 0; pt < 4; ++pt) a1[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    gemm_tile<PROD, 4, 4, false>(a1, s_h, LO0, nk1, r1, woff1, (uint32_t)ct_h * NHL * 1024u, w01, li, lg);
+    gemm_tile<PROD, 4, 4, false, true, FMT>(a1, s_h, LO0, nk1, r1, woff1, (uint32_t)ct_h * NHL * 1024u, w01, li, lg);
     w0_load<PROD, 2>(w02, r2, woff2);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(512) void swin_mlp_block_kernel(const rsa_swin_mlp_
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       uint4 uh, ul;
-      pair_units(a1[c][2 * k], a1[c][2 * k + 1], uh, ul);
+      pair_units<FMT>(a1[c][2 * k], a1[c][2 * k + 1], uh, ul);
       const int u = (2 * ct + (lg >> 1)) * SB_TOK + 16 * (2 * k + (lg & 1)) + li;
       s_h[u] = uh;
       if (PROD == 3) s_h[LO0 + u] = ul;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(512) void swin_mlp_block_kernel(const rsa_swin_mlp_
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int pt = 0; pt < 4; ++pt) a[c][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    gemm_tile<PROD, 2, 4, false>(a, s_h, LO0, nk2, r2, woff2, (uint32_t)ct_c * NHL * 1024u, w02, li, lg);
+    gemm_tile<PROD, 2, 4, false, true, FMT>(a, s_h, LO0, nk2, r2, woff2, (uint32_t)ct_c * NHL * 1024u, w02, li, lg);
     f32x4* o_img = (f32x4*)p.out + (int64_t)n * p4 * HW;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -447,8 +447,12 @@ extern "C" int rsa_swin_mlp_block(const rsa_swin_mlp_block_params* p, void* stre
     return set_error(RSA_E_ALIGN, "swin_mlp_block: pointers must be 16-byte aligned");
   const int64_t tiles = (int64_t)p->batch * (((int64_t)p->H * p->W + SB_TOK - 1) / SB_TOK);
   if (tiles > 0x3fffffff) return set_error(RSA_E_UNSUPPORTED, "swin_mlp_block: too many tokens");
+  if ((p->fmt != RSA_PF_BF16 && p->fmt != RSA_PF_F16) || p->reserved0 != 0 || (p->fmt == RSA_PF_F16 && p->products != 1))
+    return set_error(RSA_E_ARG, "swin_mlp_block: fmt must be an rsa_plane_fmt (fp16: the one-product form only)");
   if (p->products == 3)
     hipLaunchKernelGGL(swin_mlp_block_kernel<3>, dim3((unsigned)tiles), dim3(512), 0, (hipStream_t)stream, *p);
+  else if (p->fmt == RSA_PF_F16)
+    hipLaunchKernelGGL((swin_mlp_block_kernel<1, RSA_PF_F16>), dim3((unsigned)tiles), dim3(512), 0, (hipStream_t)stream, *p);
   else
     hipLaunchKernelGGL(swin_mlp_block_kernel<1>, dim3((unsigned)tiles), dim3(512), 0, (hipStream_t)stream, *p);
   const int rc = (int)hipGetLastError();

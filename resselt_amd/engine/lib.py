@@ -168,6 +168,8 @@ class SwinMlpBlockParams(C.Structure):
         ('out_lo', C.c_void_p),
         ('out_plane_stride', C.c_int64),
         ('out_batch_stride', C.c_int64),
+        ('fmt', C.c_int32),
+        ('reserved0', C.c_int32),
     ]
 
 

@@ -22,7 +22,11 @@ def mlp_block(plan, norm, fc1, fc2, n, h, w, channels, hidden, products, x_f32, 
     dev = plan.device
     g, be = norm
     mp = L.SwinMlpBlockParams()
-    mp.batch, mp.H, mp.W, mp.C, mp.hidden, mp.products, mp.eps = n, h, w, channels, hidden, products, eps
+    if fc1.products != fc2.products or fc1.fmt != fc2.fmt:
+        raise ValueError('fc1 and fc2 must be packed for the same arithmetic')
+    # (the arithmetic is what the weights were packed for: an architecture's per-layer policy may run this half in one fp16 product)
+    mp.batch, mp.H, mp.W, mp.C, mp.hidden, mp.products, mp.eps = n, h, w, channels, hidden, fc1.products, eps
+    mp.fmt = fc1.fmt
     mp.x, mp.gamma, mp.beta = x_f32.data_ptr(), g.data_ptr(), be.data_ptr()
     mp.w1, mp.b1 = fc1.packed_for(0).data_ptr(), fc1.bias.data_ptr()
     mp.w2, mp.b2 = fc2.packed_for(0).data_ptr(), fc2.bias.data_ptr()

@@ -106,7 +106,11 @@ def test_drct_vs_oracle_other_size_and_dtypes(device):
     assert yh.dtype == torch.float16 and (yh.float().cpu() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
     m.precision = 'bf16'
     assert (m(x.to(device)).cpu() - ref).abs().max().item() <= 3e-2 * max(1.0, ref.abs().max().item())
-    m.precision = 'bf16x3'
     x2 = synth.synth_input((1, 3, 70, 45), seed=10)
-    yb = m(torch.cat([x, x2]).to(device))  # a batch runs image by image through the one-image plan
-    assert yb.shape[0] == 2 and torch.equal(yb[0:1], y) and torch.equal(yb[1:2], m(x2.to(device)))
+    for precision, bar in (('bf16x3', 1e-4), ('auto', 1e-4)):
+        m.precision = precision
+        y1 = m(x.to(device))
+        assert (y1.cpu() - ref).abs().max().item() <= bar * max(1.0, ref.abs().max().item()), precision
+        yb = m(torch.cat([x, x2]).to(device))  # a batch: the per-image launch list repeated inside one plan
+        assert yb.shape[0] == 2 and torch.equal(yb[0:1], y1) and torch.equal(yb[1:2], m(x2.to(device))), precision
+    assert m.resolved_precision() == 'mixed'  # the default: Linear layers in one fp16 product
