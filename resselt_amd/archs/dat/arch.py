@@ -24,9 +24,9 @@ import torch
 
 from ...engine import lib as L
 from ...engine import ops
-from ...engine.base import EngineModule, Plan
+from ...engine.base import EngineModule, Plan, check_fp16_range
 from ...engine.paramtree import build_param_tree
-from ...engine.tensors import Planes
+from ...engine.tensors import PF_BF16, PF_F16, Planes
 from ..swinir.arch import HEAD_PAD, regroup_proj, regroup_qkv
 
 RGB_MEAN = (0.4488, 0.4371, 0.4040)  # arch.py:879
@@ -217,6 +217,18 @@ def dat_param_shapes(in_chans, embed_dim, split_size, depth, num_heads, expansio
 
 class DAT(EngineModule):
     hyperparameters = {}
+    # 'mixed' (what 'auto' selects): the two Linear layers fed by a LayerNorm -- qkv and the SGFN's fc1, 70 % of the Linear
+    # multiply-accumulates -- run ONE fp16 product on the LayerNorm's fp16 hi planes.  Everything behind them reads bf16 split planes (the
+    # rectangular-window and channel attention, the depthwise convolutions, the AIM, the spatial gate), so their outputs, proj, fc2 and the
+    # 3x3 convolutions stay in the three-product format.
+    auto_precision = 'mixed'
+    precisions = ('bf16x3', 'bf16', 'mixed')
+    precision_table = {'mixed': (3, PF_BF16)}
+
+    @staticmethod
+    def layer_policy(name: str) -> tuple[int, int]:
+        """(products, plane format of inputs and weights) of layer ``name`` under 'mixed'."""
+        return (1, PF_F16) if name.endswith(('.attn.qkv', '.ffn.fc1')) else (3, PF_BF16)
 
     def __init__(self, *, img_size=64, in_chans=3, embed_dim=180, split_size=(8, 32), depth=(6, 6, 6, 6, 6, 6), num_heads=(6, 6, 6, 6, 6, 6),
                  expansion_factor=2.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1, use_chk=False,
@@ -252,13 +264,20 @@ class DAT(EngineModule):
         def f32(t):
             return t.to(torch.float32).contiguous()
 
+        mixed = products.name == 'mixed'
+
+        def policy(name):
+            return self.layer_policy(name) if mixed else (int(products), products.fmt)
+
         def conv(name):
-            W[name] = ops.ConvWeights.from_oihw(sd[f'{name}.weight'], sd.get(f'{name}.bias'), products, device=device)
+            prod, fmt = policy(name)
+            W[name] = ops.ConvWeights.from_oihw(sd[f'{name}.weight'], sd.get(f'{name}.bias'), prod, device=device, fmt=fmt)
 
         def lin(name, w=None, b=None, cin_planes=None):
             w = sd[f'{name}.weight'] if w is None else w
             b = sd.get(f'{name}.bias') if b is None else b
-            W[name] = ops.ConvWeights.from_oihw(w[:, :, None, None], b, products, cin_planes=cin_planes, device=device)
+            prod, fmt = policy(name)
+            W[name] = ops.ConvWeights.from_oihw(w[:, :, None, None], b, prod, cin_planes=cin_planes, device=device, fmt=fmt)
 
         def ln(name):
             W[name] = (f32(sd[f'{name}.weight']), f32(sd[f'{name}.bias']))
@@ -335,6 +354,7 @@ class DAT(EngineModule):
         for name in ('conv_before_upsample.0', 'conv_last', 'upsample.0', 'upsample.2', 'upsample.4'):
             if f'{name}.weight' in sd:
                 conv(name)
+        check_fp16_range(W.values())
         W['mean'] = torch.tensor(RGB_MEAN if self.in_chans == 3 else [0.0] * self.in_chans, dtype=torch.float32, device=device)
         return W
 
@@ -402,7 +422,9 @@ class DAT(EngineModule):
 
         first = plan.f32map(n, C_, H, Wd)
         pool = [plan.f32map(n, C_, H, Wd) for _ in range(4)]
-        a_pl = plan.planes(n, cp, H, Wd, with_lo)
+        mixed = products.name == 'mixed'
+        a_pl = plan.planes(n, cp, H, Wd, **(dict(with_lo=False, fmt=PF_F16) if mixed else dict(with_lo=with_lo)))  # norm1 / norm2 -> qkv / fc1
+        n_pl = plan.planes(n, cp, H, Wd, with_lo) if mixed else a_pl  # the last LayerNorm -> conv_after_body (three products)
         qkv_pl = plan.planes(n, 3 * hp_max, H, Wd, with_lo)
         att_pl = plan.planes(n, hp_max, H, Wd, with_lo)
         conv_pl = plan.planes(n, hp_max, H, Wd, with_lo)
@@ -422,7 +444,7 @@ class DAT(EngineModule):
         wdyn = {}
         if has_dctb:
             for heads in sorted({h for h, d in zip(self.num_heads, self.depth) if d >= 2}):
-                blob = int(lib.rsa_packed_weight_bytes(heads * HEAD_PAD, heads * 4, 1, products)) // 2
+                blob = int(lib.rsa_packed_weight_bytes(heads * HEAD_PAD, heads * 4, 1, int(products))) // 2
                 wdyn[heads] = torch.zeros((n, blob), dtype=torch.bfloat16, device=dev)  # off-diagonal blocks stay zero forever
                 plan.keep.append(wdyn[heads])
 
@@ -434,6 +456,7 @@ class DAT(EngineModule):
             if out_planes is not None:
                 lp.out_hi, lp.out_lo = out_planes.hi_ptr(), out_planes.lo_ptr()
                 lp.out_plane_stride, lp.out_batch_stride = out_planes.plane_stride, out_planes.batch_stride
+                lp.out_fmt = out_planes.fmt
             lp.out_f32 = None if out_f32 is None else out_f32.data_ptr()
             launch('rsa_layernorm', lp)
 
@@ -443,7 +466,7 @@ class DAT(EngineModule):
                 ap.batch, ap.H, ap.W, ap.Hp, ap.Wp = n, H, Wd, Hp, Wp
                 ap.win_h, ap.win_w = branch_geometry(self.split_size, idx)
                 ap.shift_h, ap.shift_w = branch_geometry(shift, idx) if shifted else (0, 0)
-                ap.heads, ap.head0, ap.heads_total, ap.products = heads // 2, idx * (heads // 2), heads, products
+                ap.heads, ap.head0, ap.heads_total, ap.products = heads // 2, idx * (heads // 2), heads, int(products)
                 ap.qkv_hi, ap.qkv_lo = qkv_pl.hi_ptr(), qkv_pl.lo_ptr()
                 ap.qkv_plane_stride, ap.qkv_batch_stride = qkv_pl.plane_stride, qkv_pl.batch_stride
                 ap.bias_frag = W[f'{b}.attn.bias{idx}'].data_ptr()
@@ -454,7 +477,7 @@ class DAT(EngineModule):
         def channel_attention(b, heads):
             hp = heads * 4
             cpar = L.ChannelAttnParams()
-            cpar.batch, cpar.H, cpar.W, cpar.heads, cpar.head_dim, cpar.products = n, H, Wd, heads, C_ // heads, products
+            cpar.batch, cpar.H, cpar.W, cpar.heads, cpar.head_dim, cpar.products = n, H, Wd, heads, C_ // heads, int(products)
             cpar.q_hi, cpar.q_lo = qkv_pl.hi_ptr(0), qkv_pl.lo_ptr(0)
             cpar.k_hi, cpar.k_lo = qkv_pl.hi_ptr(hp), qkv_pl.lo_ptr(hp)
             cpar.plane_stride, cpar.batch_stride = qkv_pl.plane_stride, qkv_pl.batch_stride
@@ -463,7 +486,7 @@ class DAT(EngineModule):
             launch('rsa_channel_attention_weights', cpar)
             plan.count_launches(1)  # two kernels
             for bi in range(n):  # attn @ v: the weights differ per image
-                wts = ops.ConvWeights(wdyn[heads][bi], zero_bias, heads * HEAD_PAD, heads * HEAD_PAD, hp, 1, products)
+                wts = ops.ConvWeights(wdyn[heads][bi], zero_bias, heads * HEAD_PAD, heads * HEAD_PAD, hp, 1, int(products))
                 src = Planes(qkv_pl.hi[bi : bi + 1], None if qkv_pl.lo is None else qkv_pl.lo[bi : bi + 1])
                 dst = Planes(att_pl.hi[bi : bi + 1], None if att_pl.lo is None else att_pl.lo[bi : bi + 1])
                 plan.conv(ops.conv_params(wts, src, H, Wd, in_plane0=2 * hp, cin_planes=hp, out=dst))
@@ -568,8 +591,8 @@ class DAT(EngineModule):
             if cur is not rg_in:
                 free.append(cur)
             cur = out
-        layernorm('norm', cur, out_planes=a_pl)
-        resi_conv('conv_after_body', a_pl, first, out_planes=body_pl)  # + conv_first output (arch.py:981, 986)
+        layernorm('norm', cur, out_planes=n_pl)
+        resi_conv('conv_after_body', n_pl, first, out_planes=body_pl)  # + conv_first output (arch.py:981, 986)
 
         out_shape = (n, self.in_chans, H * s, Wd * s)
         out_buf = {'y': torch.empty(out_shape, dtype=dtype, device=dev)}
