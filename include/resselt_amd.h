@@ -432,6 +432,9 @@ typedef struct rsa_rect_attn_params {
    * 2..4 (self-attention only): DRCT's dense groups run heads of 46..122 channels (reference archs/drct/arch.py:204-329).  q planes
    * [0, 4*head_chunks*heads_total), then k, then v; out planes [(head0 + h)*4*head_chunks, +4*head_chunks). */
   int32_t head_chunks;
+  int32_t fmt;              /* enum rsa_plane_fmt of the q / k / v planes AND of the output planes (0 = bf16).  RSA_PF_F16 with products == 1: the
+                               one-product fp16 form (v_mfma_f32_32x32x16_f16; probabilities rounded to fp16) */
+  int32_t reserved0;        /* must be 0 */
 } rsa_rect_attn_params;
 int rsa_rect_attention(const rsa_rect_attn_params* p, void* stream);
 

@@ -119,11 +119,11 @@ def drct_param_shapes(in_chans, embed_dim, num_layers, num_heads, window, mlp_ra
 
 class DRCT(EngineModule):
     hyperparameters = {}
-    # 'mixed' (what 'auto' selects): the Linear layers fed by a LayerNorm or by another Linear layer -- qkv, fc1, fc2 and the 1x1 `adjust`
-    # convolutions, 85 % of the multiply-accumulates, every one of them feeding the f32 token stream through the next LayerNorm -- run ONE
-    # fp16 product on hi planes (LayerNorm outputs, hidden activations and block outputs are written as fp16 hi planes: 2 bytes per channel
-    # instead of 4).  The attention kernel reads and writes bf16 split planes, so qkv's output and proj stay in the three-product format; the
-    # 3x3 convolutions (conv_first, conv_after_body, the reconstruction head) run three bf16 products as in RRDBNet's tail.
+    # 'mixed' (what 'auto' selects): every Linear layer of a dense group (qkv, proj, fc1, fc2, the 1x1 `adjust` convolutions) and the window
+    # attention between them -- all of it feeding the f32 token stream through the next LayerNorm -- run ONE fp16 product on hi planes
+    # (LayerNorm outputs, q / k / v, softmax probabilities, attention outputs, hidden activations and block outputs are fp16 hi planes: 2
+    # bytes per channel instead of 4).  The 3x3 convolutions (conv_first, conv_after_body, the reconstruction head) run three bf16 products
+    # as in RRDBNet's tail.
     auto_precision = 'mixed'
     precisions = ('bf16x3', 'bf16', 'mixed')
     precision_table = {'mixed': (3, PF_BF16)}
@@ -131,7 +131,7 @@ class DRCT(EngineModule):
     @staticmethod
     def layer_policy(name: str) -> tuple[int, int]:
         """(products, plane format of inputs and weights) of layer ``name`` under 'mixed'."""
-        if name.endswith(('.attn.qkv', '.mlp.fc1', '.mlp.fc2')) or '.adjust' in name:
+        if name.endswith(('.attn.qkv', '.attn.proj', '.mlp.fc1', '.mlp.fc2')) or '.adjust' in name:
             return 1, PF_F16
         return 3, PF_BF16
 
@@ -272,13 +272,13 @@ class DRCT(EngineModule):
         blk = [plan.f32map(n, wide, H, Wd) for _ in range(2)]  # a Swin block's two residual sums
         max_pad = max(heads * 32 * -(-(dim // heads) // 32) for nh in self.num_heads for dim, heads, _, _ in block_dims(C_, gc, nh))
         mixed = products.name == 'mixed'
-        # 'mixed': what a one-product Linear layer reads is an fp16 hi plane (2 bytes per channel); what the attention kernel and the 3x3
-        # convolutions read stays bf16 hi + lo
+        # 'mixed': what a one-product layer (Linear or attention) reads is an fp16 hi plane (2 bytes per channel); what the 3x3 convolutions
+        # read stays bf16 hi + lo
         one = dict(with_lo=False, fmt=PF_F16) if mixed else dict(with_lo=with_lo)
         a_pl = plan.planes(n, (wide + 7) // 8, H, Wd, **one)  # LayerNorm outputs -> qkv / fc1
         n_pl = plan.planes(n, (C_ + 7) // 8, H, Wd, with_lo) if mixed else a_pl  # the last LayerNorm -> conv_after_body (three products)
-        qkv_pl = plan.planes(n, 3 * max_pad // 8, H, Wd, with_lo)
-        o_pl = plan.planes(n, max_pad // 8, H, Wd, with_lo)
+        qkv_pl = plan.planes(n, 3 * max_pad // 8, H, Wd, **one)
+        o_pl = plan.planes(n, max_pad // 8, H, Wd, **one)
         hid_pl = plan.planes(n, (int(wide * max(self.mlp_ratio, 1.0)) + 7) // 8, H, Wd, **one)
         t_pl = plan.planes(n, (wide + 7) // 8, H, Wd, **one)  # a block's output as planes (input of its adjust convolution)
         body_pl = plan.planes(n, (C_ + 7) // 8, H, Wd, with_lo)
@@ -318,7 +318,8 @@ class DRCT(EngineModule):
             ap.batch, ap.H, ap.W, ap.Hp, ap.Wp = n, H, Wd, H, Wd
             ap.win_h = ap.win_w = win
             ap.shift_h = ap.shift_w = win // 2 if shifted else 0
-            ap.heads, ap.head0, ap.heads_total, ap.products, ap.head_chunks = heads, 0, heads, int(products), chunks
+            ap.heads, ap.head0, ap.heads_total, ap.products, ap.head_chunks = heads, 0, heads, (1 if mixed else int(products)), chunks
+            ap.fmt = qkv_pl.fmt
             ap.qkv_hi, ap.qkv_lo, ap.qkv_plane_stride, ap.qkv_batch_stride = qkv_pl.hi_ptr(), qkv_pl.lo_ptr(), qkv_pl.plane_stride, qkv_pl.batch_stride
             ap.bias_frag = W[f'{name}.bias_frag'].data_ptr()
             ap.out_hi, ap.out_lo, ap.out_plane_stride, ap.out_batch_stride = o_pl.hi_ptr(), o_pl.lo_ptr(), o_pl.plane_stride, o_pl.batch_stride

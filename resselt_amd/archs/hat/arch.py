@@ -132,9 +132,9 @@ def hat_param_shapes(in_chans, embed_dim, depths, num_heads, window, compress_ra
 
 class HAT(EngineModule):
     hyperparameters = {}
-    # 'mixed' (what 'auto' selects when the MLP halves run the fused kernel): the layers fed by a LayerNorm -- qkv, the CAB's two 3x3
-    # convolutions and the fused norm2 + fc1 + GELU + fc2 half -- run ONE fp16 product on hi planes; the attention kernel reads and writes
-    # bf16 split planes, so qkv's output and proj keep the three-product format, as do the group / head convolutions.
+    # 'mixed' (what 'auto' selects when the MLP halves run the fused kernel): everything between two reads of the f32 token stream -- qkv, the
+    # window / overlapping cross-window attention, proj, the CAB's two 3x3 convolutions and the fused norm2 + fc1 + GELU + fc2 half -- runs ONE
+    # fp16 product on hi planes; the group / head convolutions keep three bf16 products.
     precisions = ('bf16x3', 'bf16', 'mixed')
     precision_table = {'mixed': (3, PF_BF16)}
 
@@ -145,7 +145,7 @@ class HAT(EngineModule):
     @staticmethod
     def layer_policy(name: str) -> tuple[int, int]:
         """(products, plane format of inputs and weights) of layer ``name`` under 'mixed'."""
-        if name.endswith(('.qkv', '.mlp.fc1', '.mlp.fc2')) or '.conv_block.cab.' in name:
+        if name.endswith(('.qkv', '.proj', '.mlp.fc1', '.mlp.fc2')) or '.conv_block.cab.' in name:
             return 1, PF_F16
         return 3, PF_BF16
 
@@ -320,8 +320,8 @@ class HAT(EngineModule):
         one = dict(with_lo=False, fmt=PF_F16) if mixed else dict(with_lo=with_lo)  # what a one-product layer reads: an fp16 hi plane
         a_pl = plan.planes(n, cp, H, Wd, **one)  # norm1 -> qkv and the CAB
         n_pl = plan.planes(n, cp, H, Wd, with_lo) if mixed else a_pl  # the last LayerNorm -> conv_after_body (three products)
-        qkv_pl = plan.planes(n, 3 * max_heads * HEAD_PAD // 8, H, Wd, with_lo)
-        o_pl = plan.planes(n, max_heads * HEAD_PAD // 8, H, Wd, with_lo)
+        qkv_pl = plan.planes(n, 3 * max_heads * HEAD_PAD // 8, H, Wd, **one)
+        o_pl = plan.planes(n, max_heads * HEAD_PAD // 8, H, Wd, **one)
         fuse_mlp = self.fused_mlp and swinblocks.mlp_block_fits(C_, hidden)
         if mixed and not fuse_mlp:
             raise NotImplementedError("HAT 'mixed' needs the fused MLP half (C <= 256, hidden <= 512); use precision 'bf16x3'")
@@ -349,7 +349,8 @@ class HAT(EngineModule):
             ap = L.RectAttnParams()
             ap.batch, ap.H, ap.W, ap.Hp, ap.Wp = n, H, Wd, H, Wd
             ap.win_h, ap.win_w, ap.shift_h, ap.shift_w = ws, ws, shift, shift
-            ap.heads, ap.head0, ap.heads_total, ap.products = heads, 0, heads, int(products)
+            ap.heads, ap.head0, ap.heads_total, ap.products = heads, 0, heads, (1 if mixed else int(products))
+            ap.fmt = qkv_pl.fmt
             ap.qkv_hi, ap.qkv_lo = qkv_pl.hi_ptr(), qkv_pl.lo_ptr()
             ap.qkv_plane_stride, ap.qkv_batch_stride = qkv_pl.plane_stride, qkv_pl.batch_stride
             ap.bias_frag = W[f'{name}.bias_frag'].data_ptr()

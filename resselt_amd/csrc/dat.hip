@@ -58,6 +58,51 @@ __device__ __forceinline__ bf16x8 pack_bf16(const float (&v)[8]) {
   return r;
 }
 
+// One-product fp16 form (round 3, FMT = RSA_PF_F16): q / k / v planes and the output planes hold fp16 values, the contractions run on
+// v_mfma_f32_32x32x16_f16.  The 16-byte units, the LDS images and the transpose reads are format-agnostic (16-bit elements); what
+// changes is the matrix instruction, how the probabilities are packed and how the output is rounded.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+template <int FMT>
+__device__ __forceinline__ f32x16 mfma32(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+  if constexpr (FMT == RSA_PF_F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <int FMT>
+__device__ __forceinline__ bf16x8 pack16(const float (&v)[8]) {
+  if constexpr (FMT == RSA_PF_F16) {
+    f16x8_t h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (_Float16)v[j];
+    return __builtin_bit_cast(bf16x8, h);
+  } else {
+    return pack_bf16(v);
+  }
+}
+// four output values -> the 8-byte half of a plane unit (hi, and the rounding residual for a lo plane)
+template <int FMT>
+__device__ __forceinline__ void round4(const float (&v)[4], bf16x4& h, bf16x4& lo4) {
+  if constexpr (FMT == RSA_PF_F16) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+    f16x4_t hh, ll;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hh[e] = (_Float16)v[e];
+      ll[e] = (_Float16)(v[e] - (float)hh[e]);
+    }
+    h = __builtin_bit_cast(bf16x4, hh);
+    lo4 = __builtin_bit_cast(bf16x4, ll);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const __bf16 hb = (__bf16)v[e];
+      h[e] = hb;
+      lo4[e] = (__bf16)(v[e] - (float)hb);
+    }
+  }
+}
+
 // One workgroup (4 waves) = one (window, head).  T = tiles of 32 tokens the LDS images hold.
 //   self mode  (kwin == 0): keys = the window's own tokens (<= 32*T), staged once;
 //   cross mode (kwin > 0) : keys = the (kwin_h x kwin_w) window that starts kpad pixels up-left of the query window (HAT's
@@ -65,7 +110,7 @@ __device__ __forceinline__ bf16x8 pack_bf16(const float (&v)[8]) {
 //                           32*T keys; the flash-style running max / sum / output of a wave's (up to two) query tiles live in
 //                           registers across the chunks.
 // K and V of a chunk are staged once in LDS; wave w owns query tiles w and w + 4.
-template <int PROD, int T>
+template <int PROD, int T, int FMT = 0>
 __global__ __launch_bounds__(256, 2) void rect_attention_kernel(const rsa_rect_attn_params p) {
   constexpr int NT = 32 * T;
   constexpr int KROW = 40;  // bf16 per K row = 80 bytes: ds_read_b128 of 16 consecutive rows touches every bank once
@@ -206,10 +251,10 @@ __global__ __launch_bounds__(256, 2) void rect_attention_kernel(const rsa_rect_a
           const bf16x8 kh = *(const bf16x8*)&s_k[0][off];
           if (PROD == 3) {
             const bf16x8 kl = *(const bf16x8*)&s_k[NHL - 1][off];
-            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[qi][s], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[qi][s], a, 0, 0, 0);
+            a = mfma32<FMT>(kl, qh[qi][s], a);
+            a = mfma32<FMT>(kh, ql[qi][s], a);
           }
-          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[qi][s], a, 0, 0, 0);
+          a = mfma32<FMT>(kh, qh[qi][s], a);
         }
         // + position bias (pre-gathered per (query tile, key tile), -1e30 on padded keys) + shift mask
         const f32x4* bf = (const f32x4*)(p.bias_frag + ((((int64_t)head * QTB + qt) * KT + kt0 + kt) * 64 + lane) * 16);
@@ -261,15 +306,15 @@ __global__ __launch_bounds__(256, 2) void rect_attention_kernel(const rsa_rect_a
           float e8[8], r8[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) e8[j] = a[8 * s + j];
-          const bf16x8 ph = pack_bf16(e8);
+          const bf16x8 ph = pack16<FMT>(e8);
           if (PROD == 3) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) r8[j] = e8[j] - (float)ph[j];
             const bf16x8 pl = pack_bf16(r8);
-            ot[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, ot[qi], 0, 0, 0);
-            ot[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, ot[qi], 0, 0, 0);
+            ot[qi] = mfma32<FMT>(vl, ph, ot[qi]);
+            ot[qi] = mfma32<FMT>(vh, pl, ot[qi]);
           }
-          ot[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, ot[qi], 0, 0, 0);
+          ot[qi] = mfma32<FMT>(vh, ph, ot[qi]);
         }
       }
     }
@@ -286,13 +331,10 @@ __global__ __launch_bounds__(256, 2) void rect_attention_kernel(const rsa_rect_a
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       bf16x4 h, lo4;
+      float v4[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float v = ot[qi][g * 4 + e] * inv_l;
-        const __bf16 hb = (__bf16)v;
-        h[e] = hb;
-        lo4[e] = (__bf16)(v - (float)hb);
-      }
+      for (int e = 0; e < 4; ++e) v4[e] = ot[qi][g * 4 + e] * inv_l;
+      round4<FMT>(v4, h, lo4);
       const int64_t off = (((int64_t)slot * 4 + g) * p.out_plane_stride + qpix[qi]) * 16 + lh * 8;
       *(bf16x4*)(out_hi + off) = h;
       if (out_lo != nullptr) *(bf16x4*)(out_lo + off) = lo4;
@@ -306,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void rect_attention_kernel(const rsa_rect_a
 // planes.  Same mathematics and fragment orders as rect_attention_kernel; what changes is the staging: the K / V images of a whole
 // 256-token window no longer fit LDS at 128 channels, so keys are staged 64 at a time (two key tiles, all chunks) and the running
 // max / sum / output of a wave's query tile carry over the stages, flash style.  8 waves, wave w owns query tile w.
-template <int PROD, int DC>
+template <int PROD, int DC, int FMT = 0>
 __global__ __launch_bounds__(512, 1) void rect_attention_wide_kernel(const rsa_rect_attn_params p, int TB) {
   constexpr int TS = 2;          // key tiles per stage
   constexpr int NK = 32 * TS;    // keys per stage
@@ -429,10 +471,10 @@ __global__ __launch_bounds__(512, 1) void rect_attention_wide_kernel(const rsa_r
           const bf16x8 kh = *(const bf16x8*)&s_k[0][c][off];
           if (PROD == 3) {
             const bf16x8 kl = *(const bf16x8*)&s_k[NHL - 1][c][off];
-            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[c][s], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[c][s], a, 0, 0, 0);
+            a = mfma32<FMT>(kl, qh[c][s], a);
+            a = mfma32<FMT>(kh, ql[c][s], a);
           }
-          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[c][s], a, 0, 0, 0);
+          a = mfma32<FMT>(kh, qh[c][s], a);
         }
       const f32x4* bf = (const f32x4*)(p.bias_frag + ((((int64_t)head * TB + qt) * TB + kt0 + kt) * 64 + lane) * 16);
       float tm = -3.0e38f;
@@ -471,7 +513,7 @@ __global__ __launch_bounds__(512, 1) void rect_attention_wide_kernel(const rsa_r
         float e8[8], r8[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) e8[j] = a[8 * s + j];
-        const bf16x8 ph = pack_bf16(e8);
+        const bf16x8 ph = pack16<FMT>(e8);
         bf16x8 pl8 = zero8;
         if (PROD == 3) {
 #pragma unroll
@@ -495,10 +537,10 @@ __global__ __launch_bounds__(512, 1) void rect_attention_wide_kernel(const rsa_r
             }
           }
           if (PROD == 3) {
-            ot[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, ot[c], 0, 0, 0);
-            ot[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl8, ot[c], 0, 0, 0);
+            ot[c] = mfma32<FMT>(vl, ph, ot[c]);
+            ot[c] = mfma32<FMT>(vh, pl8, ot[c]);
           }
-          ot[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, ot[c], 0, 0, 0);
+          ot[c] = mfma32<FMT>(vh, ph, ot[c]);
         }
       }
     }
@@ -515,13 +557,10 @@ __global__ __launch_bounds__(512, 1) void rect_attention_wide_kernel(const rsa_r
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       bf16x4 h, lo4;
+      float v4[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float v = ot[c][g * 4 + e] * inv_l;
-        const __bf16 hb = (__bf16)v;
-        h[e] = hb;
-        lo4[e] = (__bf16)(v - (float)hb);
-      }
+      for (int e = 0; e < 4; ++e) v4[e] = ot[c][g * 4 + e] * inv_l;
+      round4<FMT>(v4, h, lo4);
       const int64_t off = ((((int64_t)slot * DC + c) * 4 + g) * p.out_plane_stride + qpix) * 16 + lh * 8;
       *(bf16x4*)(out_hi + off) = h;
       if (out_lo != nullptr) *(bf16x4*)(out_lo + off) = lo4;
@@ -880,6 +919,8 @@ extern "C" int rsa_rect_attention(const rsa_rect_attn_params* p, void* stream) {
   if (p->shift_h < 0 || p->shift_h >= p->win_h || p->shift_w < 0 || p->shift_w >= p->win_w || ((p->shift_h == 0) != (p->shift_w == 0)))
     return set_error(RSA_E_ARG, "rect_attention: shifts must both be 0 or both be in (0, window)");
   if (p->products != 1 && p->products != 3) return set_error(RSA_E_UNSUPPORTED, "rect_attention: products must be 1 or 3");
+  if ((p->fmt != RSA_PF_BF16 && p->fmt != RSA_PF_F16) || p->reserved0 != 0 || (p->fmt == RSA_PF_F16 && p->products != 1))
+    return set_error(RSA_E_ARG, "rect_attention: fmt must be an rsa_plane_fmt (fp16 planes: the one-product form only)");
   if (!p->qkv_hi || !p->bias_frag || !p->out_hi || (p->products == 3 && !p->qkv_lo)) return set_error(RSA_E_ARG, "rect_attention: null pointer");
   if (misaligned(p->qkv_hi) || misaligned(p->qkv_lo) || misaligned(p->bias_frag) || misaligned(p->out_hi) || misaligned(p->out_lo))
     return set_error(RSA_E_ALIGN, "rect_attention: pointers must be 16-byte aligned");
@@ -902,6 +943,10 @@ extern "C" int rsa_rect_attention(const rsa_rect_attn_params* p, void* stream) {
 #define RSA_RAW(PROD, DC) hipLaunchKernelGGL((rect_attention_wide_kernel<PROD, DC>), gridw, blockw, 0, s, *p, T)
     if (p->products == 3) {
       if (DCh == 2) RSA_RAW(3, 2); else if (DCh == 3) RSA_RAW(3, 3); else RSA_RAW(3, 4);
+    } else if (p->fmt == RSA_PF_F16) {
+#define RSA_RAWH(DC) hipLaunchKernelGGL((rect_attention_wide_kernel<1, DC, RSA_PF_F16>), gridw, blockw, 0, s, *p, T)
+      if (DCh == 2) RSA_RAWH(2); else if (DCh == 3) RSA_RAWH(3); else RSA_RAWH(4);
+#undef RSA_RAWH
     } else {
       if (DCh == 2) RSA_RAW(1, 2); else if (DCh == 3) RSA_RAW(1, 3); else RSA_RAW(1, 4);
     }
@@ -913,6 +958,10 @@ extern "C" int rsa_rect_attention(const rsa_rect_attn_params* p, void* stream) {
 #define RSA_RA(PROD, TT) hipLaunchKernelGGL((rect_attention_kernel<PROD, TT>), grid, block, 0, s, *p)
   if (p->products == 3) {
     if (T == 1) RSA_RA(3, 1); else if (T == 2) RSA_RA(3, 2); else if (T == 4) RSA_RA(3, 4); else RSA_RA(3, 8);
+  } else if (p->fmt == RSA_PF_F16) {
+#define RSA_RAH(TT) hipLaunchKernelGGL((rect_attention_kernel<1, TT, RSA_PF_F16>), grid, block, 0, s, *p)
+    if (T == 1) RSA_RAH(1); else if (T == 2) RSA_RAH(2); else if (T == 4) RSA_RAH(4); else RSA_RAH(8);
+#undef RSA_RAH
   } else {
     if (T == 1) RSA_RA(1, 1); else if (T == 2) RSA_RA(1, 2); else if (T == 4) RSA_RA(1, 4); else RSA_RA(1, 8);
   }

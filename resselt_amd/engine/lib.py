@@ -265,6 +265,8 @@ class RectAttnParams(C.Structure):
         ('kpad_h', C.c_int32),
         ('kpad_w', C.c_int32),
         ('head_chunks', C.c_int32),
+        ('fmt', C.c_int32),
+        ('reserved0', C.c_int32),
     ]
 
 
