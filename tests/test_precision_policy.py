@@ -81,3 +81,30 @@ def test_span_mixed_policy_on_spanplus_x4():
             one = (O.spanplus_forward(sd, x) - ref).abs().max().item()
     print(mixed, one)
     assert mixed <= 2e-5 and one > 1e-4
+
+
+def test_transformer_policies_name_the_one_product_layers():
+    """DRCT / HAT / DAT under 'mixed' (the default): which layers run ONE fp16 product.  The GPU suite pins the resulting error on the
+    reference vectors (<= 1e-4 * max(1, |y|)); this test pins the tables themselves."""
+    from resselt_amd.archs.dat.arch import DAT
+    from resselt_amd.archs.drct.arch import DRCT
+    from resselt_amd.archs.hat.arch import HAT
+    from resselt_amd.engine.tensors import PF_BF16, PF_F16
+
+    one, three = (1, PF_F16), (3, PF_BF16)
+    b = 'layers.0.swin3'
+    assert [DRCT.layer_policy(f'{b}.{n}') for n in ('attn.qkv', 'attn.proj', 'mlp.fc1', 'mlp.fc2')] == [one] * 4
+    assert DRCT.layer_policy('layers.2.adjust4') == one and DRCT.layer_policy('conv_after_body') == three and DRCT.layer_policy('conv_last') == three
+    h = 'layers.1.residual_group.blocks.2'
+    assert [HAT.layer_policy(f'{h}.{n}') for n in ('attn.qkv', 'attn.proj', 'conv_block.cab.0', 'conv_block.cab.2', 'mlp.fc1', 'mlp.fc2')] == [one] * 6
+    assert HAT.layer_policy('layers.1.residual_group.overlap_attn.qkv') == one and HAT.layer_policy('layers.1.conv') == three
+    d = 'layers.0.blocks.1'
+    assert DAT.layer_policy(f'{d}.attn.qkv') == one and DAT.layer_policy(f'{d}.ffn.fc1') == one
+    assert DAT.layer_policy(f'{d}.attn.proj') == three and DAT.layer_policy(f'{d}.ffn.fc2') == three and DAT.layer_policy('conv_first') == three
+    sd = synth.drct_state_dict(num_layers=1, embed_dim=60, gc=16, window=8)
+    import resselt_amd
+
+    m = resselt_amd.load_from_state_dict(dict(sd))
+    assert m.precision == 'auto' and m.resolved_precision() == 'mixed'
+    m.precision = 'bf16x3'
+    assert m.resolved_precision() == 'bf16x3'
