@@ -298,6 +298,9 @@ int gemm_k1_launch(const rsa_conv_params& p, hipStream_t stream) {
     if (nq <= 8) return launch_gemm<3, 2, 8, 64>(p, stream);
     if (nq <= 16) return launch_gemm<3, 1, 16, 32>(p, stream);
   } else {
+    // one product: a K of at most 256 channels takes the 8-chunk image (2 x 32 KB of LDS: two workgroups per CU, which the register budget of
+    // the kernel already allows; the 16-chunk image fills the LDS with one)
+    if (nq <= 8) return p.in_fmt == RSA_PF_F16 ? launch_gemm<1, 2, 8, 64, RSA_PF_F16>(p, stream) : launch_gemm<1, 2, 8, 64>(p, stream);
     if (nq <= 16) return p.in_fmt == RSA_PF_F16 ? launch_gemm<1, 2, 16, 64, RSA_PF_F16>(p, stream) : launch_gemm<1, 2, 16, 64>(p, stream);
   }
   return -100;
