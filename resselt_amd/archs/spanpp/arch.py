@@ -18,7 +18,8 @@ from ...engine import lib as L
 from ...engine import ops
 from ...engine.base import EngineModule, Plan
 from ...engine.paramtree import build_param_tree
-from ...engine.spanblocks import SpabChain, conv3xc_shapes, fold_conv3xc
+from ...engine.base import check_fp16_range
+from ...engine.spanblocks import SPAN_FIRST, SPAN_MIXED, SpabChain, conv3xc_shapes, fold_conv3xc, span_layer_policy
 
 
 def repconv_shapes(shapes: dict, name: str, cout: int, cin: int) -> None:
@@ -111,16 +112,31 @@ class SpanPP(EngineModule):
         state_dict['MetaIGConv'] = self.MetaIGConv  # the reference injects its own buffer the same way (arch.py:354-356)
         return state_dict
 
+    # 'mixed' (what 'auto' selects; engine/spanblocks.py::SPAN_MIXED, as SPANPlus): the re-parameterised 3x3 convolutions behind a SPAB gate in ONE
+    # fp16 product on hi planes; the first convolution, conv_cat and the implicit upsampler's 3x3 kernel in three fp16 products.
+    auto_precision = 'mixed'
+    precisions = ('bf16x3', 'bf16', 'fp16', 'mixed')
+    precision_table = SPAN_MIXED
+
     def _pack(self, device, products):
         sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}  # folds and the IGConv kernel are host-side weight preprocessing (f64 / f32)
         fsd = {k: (v.to(torch.float32) if v.is_floating_point() else v) for k, v in sd.items()}
+        mixed = products.name == 'mixed'
+
+        def policy(name, conv3xc):
+            return span_layer_policy(name, conv3xc) if mixed else (int(products), products.fmt)
+
         W = {}
         for name in self._rep_names:
             w, b = fold_repconv(fsd, name)
-            W[name] = ops.ConvWeights.from_oihw(w, b, products, device=device)
-        W['conv_cat'] = ops.ConvWeights.from_oihw(fsd['conv_cat.weight'], fsd['conv_cat.bias'], products, device=device)
+            prod, fmt = policy(name, True)
+            # (the first convolution is packed over a whole 16-channel half chunk: its input carries a second, all-zero plane -> ring schedule)
+            W[name] = ops.ConvWeights.from_oihw(w, b, prod, device=device, fmt=fmt, cin_planes=2 if name in SPAN_FIRST and w.shape[1] <= 8 else None)
+        prod, fmt = policy('conv_cat', False)
+        W['conv_cat'] = ops.ConvWeights.from_oihw(fsd['conv_cat.weight'], fsd['conv_cat.bias'], prod, device=device, fmt=fmt)
         for s in self.scale_list:
-            W[f'up{s}'] = ops.ConvWeights.from_oihw(igconv_kernel(fsd, s, max(self.scale_list)), None, products, device=device)
+            W[f'up{s}'] = ops.ConvWeights.from_oihw(igconv_kernel(fsd, s, max(self.scale_list)), None, prod, device=device, fmt=fmt)
+        check_fp16_range(W.values())
         return W
 
     def macs_per_input_pixel(self) -> int:
@@ -143,15 +159,21 @@ class SpanPP(EngineModule):
             raise RuntimeError(f'model expects {self.in_channels} input channels, got {c}')
         fc, pf, s = self.fc, self.fc // 8, self._scale
         with_lo = products == 3
-        x_pl = plan.planes(n, (c + 7) // 8, h, w, with_lo)
-        chain = SpabChain(plan, W, n, h, w, fc, L.ACT_SILU, with_lo)
+        wide = with_lo or products.name == 'mixed'  # buffers read by a three-product layer (conv_cat, the head) keep hi + lo
+        ring_first = W['conv0'].cin_planes == 2  # a second, all-zero input plane: the first convolution takes the ring schedule (see SpanPlus)
+        x_pl = plan.planes(n, 2 if ring_first else (c + 7) // 8, h, w, wide)
+        if ring_first:
+            x_pl.hi.zero_()
+            if x_pl.lo is not None:
+                x_pl.lo.zero_()
+        chain = SpabChain(plan, W, n, h, w, fc, L.ACT_SILU, with_lo, cat_lo=wide)
 
         def set_input(x):
             ops.nchw_to_planes(x, x_pl)
 
         cat = chain.new_cat()
-        xf = plan.f32map(n, fc, h, w)
-        feat = plan.planes(n, pf, h, w, with_lo)
+        xf = None if chain.plane_shortcut else plan.f32map(n, fc, h, w)  # (the gate's shortcut as an f32 map: plain-bf16 mode only)
+        feat = plan.planes(n, pf, h, w, wide)
         plan.conv(ops.conv_params(W['conv0'], x_pl, h, w, out=cat, out_plane_off=0, out_f32=xf))
         names = dict(first='block_1', middle=[f'block_{i}' for i in range(2, 6)], end='block_6', conv_2='conv_2', conv_cat='conv_cat')
         chain.run(names, cat, xf, feat, 0, None)

@@ -125,7 +125,7 @@ class SpabChain:
 #: (tests/test_precision_policy.py): 4e-6 max-abs against fp32 where one product everywhere gives 2.1e-4 (conv_cat, the head and the first
 #: convolution contribute 0.7-1.6e-4 each) -- with fp16 output tensors the former is half an ulp of the output, the latter is not.
 SPAN_MIXED = {'mixed': (1, PF_F16)}
-SPAN_FIRST = ('feats.0', 'conv_1')  # the first convolution of SPANPlus / SPAN
+SPAN_FIRST = ('feats.0', 'conv_1', 'conv0')  # the first convolution of SPANPlus / SPAN / SpanPP
 
 
 def span_layer_policy(name: str, conv3xc: bool) -> tuple[int, int]:
