@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RSA_VERSION 300 /* 0.3.0: plane formats (fp16 one-product mode), rsa_check_status, rsa_pack_weights(fmt) */
+#define RSA_VERSION 400 /* 0.4.0: rsa_conv2d_pair (cross-layer fusion of residual dense block convolutions), fp16 saturation + overflow status */
 
 /* error codes (negative = argument errors) */
 #define RSA_OK 0
@@ -156,6 +156,17 @@ typedef struct rsa_conv_params {
 int rsa_conv2d(const rsa_conv_params* p, void* stream);
 int rsa_conv2d_list(const rsa_conv_params* list, int32_t n, void* stream);
 
+/* Cross-layer fusion of a residual dense block (SURVEY.md 8b `sr_rdb_fused`; reference utilities/block.py:454-465): descriptors `a` and `b`
+ * are a FUSABLE PAIR when b is the growth convolution that follows a in the block -- both 3x3, one fp16 product, 32 output channels, bias +
+ * LeakyReLU / linear into hi-only fp16 planes, a writing the four planes right behind its own input planes and b reading a's input planes
+ * plus those four (conv1 -> conv2, conv3 -> conv4).  rsa_conv2d_pair runs both in one launch that streams the common input through LDS once
+ * (b's last 32 input channels never leave the chip before b has used them; a's output is still written for the later layers); the result
+ * is bit-identical to rsa_conv2d(a) followed by rsa_conv2d(b).  rsa_conv2d_list fuses such neighbours by itself unless RSA_CONV_PAIR=0
+ * is set in the environment.  rsa_conv_pair_fusable: 1 when the list would fuse (a, b), else 0.  rsa_conv2d_pair on anything else:
+ * RSA_E_UNSUPPORTED.  Both descriptors carry their own packed weights (layout 1), exactly as for separate launches. */
+int rsa_conv2d_pair(const rsa_conv_params* a, const rsa_conv_params* b, void* stream);
+int rsa_conv_pair_fusable(const rsa_conv_params* a, const rsa_conv_params* b);
+
 /* Failure word of the ring schedule (csrc/conv_ring.h: a hand-off between the loader wave and the compute waves that timed out makes the
  * kernel drain with wrong pixels).  The kernels report into host-visible memory, so this call never synchronises: it sees the failures of
  * every launch that has COMPLETED.  Call it after the stream (or an event behind the forward) has been synchronised to judge that forward.
@@ -199,6 +210,8 @@ int rsa_debug_set_ring_spin_limit(int32_t polls);
 /* Debug: force the ring schedule on (1) / off (0) for descriptors built afterwards, or follow RSA_CONV_RING again (-1).  Descriptors carry
  * the layout they were built for, so change it only between building descriptor sets (in-process A/B timing). */
 int rsa_debug_set_ring(int32_t mode);
+/* Debug: pair fusion inside rsa_conv2d_list on (1) / off (0), or follow RSA_CONV_PAIR again (-1): in-process A/B timing. */
+int rsa_debug_set_pair(int32_t mode);
 
 /*
  * Plain NCHW tensor [N][C][src_h][src_w] -> split planes of size H x W, with per-channel affine v = (x - mean[c]) * scale.

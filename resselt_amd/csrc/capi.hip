@@ -165,18 +165,51 @@ int rsa_conv2d(const rsa_conv_params* p, void* stream) {
   return rsa::conv_launch(*p, (hipStream_t)stream);
 }
 
+static int list_error(int rc, int i) {
+  char buf[200];
+  snprintf(buf, sizeof(buf), "rsa_conv2d_list: entry %d: %.150s", i, rsa::g_err);
+  strncpy(rsa::g_err, buf, sizeof(rsa::g_err) - 1);  // keep the hip error text that conv_launch recorded
+  return rc;
+}
+
 int rsa_conv2d_list(const rsa_conv_params* list, int32_t n, void* stream) {
   if (list == nullptr || n < 0) return rsa::set_error(RSA_E_ARG, "rsa_conv2d_list: null list");
+  const bool fuse = rsa::conv_pair_enabled();
   for (int32_t i = 0; i < n; ++i) {
-    const int rc = rsa::conv_launch(list[i], (hipStream_t)stream);
-    if (rc != RSA_OK) {
-      char buf[200];
-      snprintf(buf, sizeof(buf), "rsa_conv2d_list: entry %d: %.150s", i, rsa::g_err);
-      // keep the hip error text that conv_launch recorded
-      strncpy(rsa::g_err, buf, sizeof(rsa::g_err) - 1);
-      return rc;
+    // cross-layer fusion: two consecutive growth convolutions of a residual dense block run as ONE launch (conv_ring_pair.h)
+    if (fuse && i + 1 < n && rsa::conv_pair_eligible(list[i], list[i + 1])) {
+      int rc = rsa::conv_validate(list[i]);
+      if (rc != RSA_OK) return list_error(rc, i);
+      rc = rsa::conv_validate(list[i + 1]);
+      if (rc != RSA_OK) return list_error(rc, i + 1);
+      rc = rsa::conv_launch_pair(list[i], list[i + 1], (hipStream_t)stream);
+      if (rc != 0) return list_error(rsa::set_error(rc, "conv: pair kernel launch failed"), i);
+      ++i;
+      continue;
     }
+    const int rc = rsa::conv_launch(list[i], (hipStream_t)stream);
+    if (rc != RSA_OK) return list_error(rc, i);
   }
+  return RSA_OK;
+}
+
+int rsa_conv2d_pair(const rsa_conv_params* a, const rsa_conv_params* b, void* stream) {
+  if (a == nullptr || b == nullptr) return rsa::set_error(RSA_E_ARG, "rsa_conv2d_pair: null params");
+  if (!rsa::conv_pair_eligible(*a, *b)) return rsa::set_error(RSA_E_UNSUPPORTED, "rsa_conv2d_pair: the two descriptors are not a fusable pair (ask rsa_conv_pair_fusable)");
+  int rc = rsa::conv_validate(*a);
+  if (rc != RSA_OK) return rc;
+  rc = rsa::conv_validate(*b);
+  if (rc != RSA_OK) return rc;
+  rc = rsa::conv_launch_pair(*a, *b, (hipStream_t)stream);
+  return rc ? rsa::set_error(rc, "conv: pair kernel launch failed") : RSA_OK;
+}
+
+int rsa_conv_pair_fusable(const rsa_conv_params* a, const rsa_conv_params* b) {
+  return a != nullptr && b != nullptr && rsa::conv_pair_enabled() && rsa::conv_pair_eligible(*a, *b) ? 1 : 0;
+}
+
+int rsa_debug_set_pair(int32_t mode) {
+  rsa::conv_pair_override(mode);
   return RSA_OK;
 }
 

@@ -12,6 +12,7 @@ int set_error(int code, const char* msg);
 
 // conv_mfma.hip
 int conv_launch(const rsa_conv_params& p, hipStream_t stream);
+int conv_validate(const rsa_conv_params& p);  // every argument check of conv_launch, nothing launched
 int conv_nct(int cout);
 const char* conv_kernel_name(const rsa_conv_params& p);
 
@@ -66,6 +67,23 @@ inline bool conv_ring_up2_eligible(const rsa_conv_params& p) {
          p.out_lo != nullptr && p.out_f32 == nullptr && p.out_nchw == nullptr && p.res1 == nullptr && p.res2 == nullptr && p.res1_hi == nullptr &&
          p.res2_hi == nullptr && (p.act == RSA_ACT_NONE || (p.act == RSA_ACT_LRELU && p.act_param >= 0.f && p.act_param <= 1.f));
 }
+// Cross-layer fusion (conv_ring_pair.h): two CONSECUTIVE growth convolutions of a residual dense block -- conv1 -> conv2 or conv3 -> conv4 of
+// utilities/block.py:454-465 -- run as one launch that streams their common input planes through LDS once.  (a, b) is such a pair iff both are
+// one-product fp16 3x3 layers with 32 output channels and a bias + LeakyReLU / linear hi-only plane epilogue (conv_ring_em1_eligible), a writes the
+// four planes right behind its own input planes in the same buffer and b reads exactly a's input planes + those four (the dense concatenation).
+// RSA_CONV_PAIR=0 in the environment (or rsa_debug_set_pair(0)) makes rsa_conv2d_list launch them one by one again (A/B runs).
+bool conv_pair_enabled();
+void conv_pair_override(int v);
+inline bool conv_pair_eligible(const rsa_conv_params& a, const rsa_conv_params& b) {
+  return a.ksize == 3 && b.ksize == 3 && !a.upsample2x && !b.upsample2x && a.cout == 32 && b.cout == 32 && conv_ring_em1_eligible(a) && conv_ring_em1_eligible(b) &&
+         a.w_layout == RSA_WL_PAIRS && b.w_layout == RSA_WL_PAIRS && a.cin_planes >= 4 && (a.cin_planes & 3) == 0 && b.cin_planes == a.cin_planes + 4 &&
+         a.batch == b.batch && a.H == b.H && a.W == b.W && a.in_hi == b.in_hi && a.in_plane_stride == b.in_plane_stride && a.in_batch_stride == b.in_batch_stride &&
+         a.out_hi == a.in_hi && a.out_plane_off == a.cin_planes && a.out_plane_stride == a.in_plane_stride && a.out_batch_stride == a.in_batch_stride &&
+         (b.out_hi != b.in_hi || b.out_plane_off >= b.cin_planes) && a.w_packed != nullptr && b.w_packed != nullptr;
+}
+int conv_launch_pair(const rsa_conv_params& a, const rsa_conv_params& b, hipStream_t stream);  // conv_inst_ringpair.hip; the caller has validated both
+unsigned int conv_ring_pair_aborts();
+
 inline int conv_ring_layout(const rsa_conv_params& p) {
   if (conv_up2_enabled() && conv_ring_up2_eligible(p)) return RSA_WL_UPPHASE;
   return (p.cin_planes & 3) == 0 ? RSA_WL_PAIRS : RSA_WL_HALFPAIRS;

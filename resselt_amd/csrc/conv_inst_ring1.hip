@@ -27,7 +27,7 @@ int conv_launch_ring(const rsa_conv_params& p, hipStream_t stream) {
 
 unsigned int conv_ring_aborts() {
   return ring_aborts_this_unit() + conv_ring2_aborts() + conv_ring3_aborts() + conv_ring_up2_aborts() + conv_ring1h_aborts() + conv_ring2h_aborts() + conv_ring3h_aborts() +
-         conv_ring3hx_aborts();
+         conv_ring3hx_aborts() + conv_ring_pair_aborts();
 }
 }  // namespace rsa
 

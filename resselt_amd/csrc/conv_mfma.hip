@@ -121,7 +121,8 @@ int conv_nct(int cout) {
   return (w3 < w4) ? 3 : 4;
 }
 
-int conv_launch(const rsa_conv_params& p, hipStream_t stream) {
+// every argument check of a descriptor, nothing launched (rsa_conv2d_list validates both halves of a fused pair with it)
+int conv_validate(const rsa_conv_params& p) {
   if (p.batch < 1 || p.H < 1 || p.W < 1 || p.cin_planes < 1 || p.cout < 1) return set_error(RSA_E_ARG, "conv: bad geometry");
   if (p.ksize != 1 && p.ksize != 3) return set_error(RSA_E_UNSUPPORTED, "conv: ksize must be 1 or 3");
   if (p.products != 1 && p.products != 3) return set_error(RSA_E_UNSUPPORTED, "conv: products must be 1 or 3");
@@ -164,11 +165,20 @@ int conv_launch(const rsa_conv_params& p, hipStream_t stream) {
                                                  : conv_ring_eligible(p) && p.w_layout == ((p.cin_planes & 3) == 0 ? RSA_WL_PAIRS : RSA_WL_HALFPAIRS);
     if (!ok) return set_error(RSA_E_ARG, "conv: w_layout 1 / 2 / 3 on a descriptor the ring schedule does not take that way (ask rsa_conv_weight_layout)");
     if (p.in_plane_stride * 32 >= (int64_t)1 << 32) return set_error(RSA_E_UNSUPPORTED, "conv: input plane too large for 32-bit lane offsets; band the image");
-    const int rc = conv_launch_ring(p, stream);
-    return rc ? set_error(rc, "conv: ring kernel launch failed") : RSA_OK;
+    return RSA_OK;
   }
   if (p.in_fmt == RSA_PF_F16 && p.products == 3 && p.upsample2x)
     return set_error(RSA_E_UNSUPPORTED, "conv: three fp16 products are not compiled with a fused x2 upsampling (use bf16 planes for that layer)");
+  return RSA_OK;
+}
+
+int conv_launch(const rsa_conv_params& p, hipStream_t stream) {
+  const int vrc = conv_validate(p);
+  if (vrc != RSA_OK) return vrc;
+  if (p.w_layout != RSA_WL_TAPS) {  // ring schedule (conv_ring.h)
+    const int rc = conv_launch_ring(p, stream);
+    return rc ? set_error(rc, "conv: ring kernel launch failed") : RSA_OK;
+  }
   if (p.ksize == 1) {  // wide k1 layers (nn.Linear over tokens): weight-stationary GEMM schedule, gemm_k1.hip
     const int g = gemm_k1_launch(p, stream);
     if (g != -100) return g == 0 ? RSA_OK : set_error(g, "conv: gemm_k1 launch failed");

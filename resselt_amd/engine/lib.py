@@ -416,6 +416,9 @@ EXPORTS = (
     'rsa_debug_ring_aborts',
     'rsa_debug_set_ring_spin_limit',
     'rsa_debug_set_ring',
+    'rsa_debug_set_pair',
+    'rsa_conv2d_pair',
+    'rsa_conv_pair_fusable',
     'rsa_nchw_to_planes',
     'rsa_planes_to_nchw',
     'rsa_dysample',
@@ -508,6 +511,12 @@ def load() -> C.CDLL:
     lib.rsa_debug_ring_aborts.restype = C.c_int
     lib.rsa_debug_set_ring.argtypes = [C.c_int32]
     lib.rsa_debug_set_ring.restype = C.c_int
+    lib.rsa_debug_set_pair.argtypes = [C.c_int32]
+    lib.rsa_debug_set_pair.restype = C.c_int
+    lib.rsa_conv2d_pair.argtypes = [C.POINTER(ConvParams), C.POINTER(ConvParams), C.c_void_p]
+    lib.rsa_conv2d_pair.restype = C.c_int
+    lib.rsa_conv_pair_fusable.argtypes = [C.POINTER(ConvParams), C.POINTER(ConvParams)]
+    lib.rsa_conv_pair_fusable.restype = C.c_int
     lib.rsa_debug_set_ring_spin_limit.argtypes = [C.c_int32]
     lib.rsa_debug_set_ring_spin_limit.restype = C.c_int
     lib.rsa_check_status.argtypes = []
@@ -593,6 +602,20 @@ def check_status(what: str = 'forward') -> None:
     """Raise when a ring-schedule kernel of a COMPLETED launch reported a failed hand-off (``rsa_check_status``: reads a host-visible word,
     never synchronises).  Synchronise the stream first to judge the launches still in flight."""
     check(load().rsa_check_status(), f'{what}: rsa_check_status')
+
+
+def conv2d_pair(a: ConvParams, b: ConvParams, stream: int) -> None:
+    """Two consecutive growth convolutions of a residual dense block as ONE launch (``rsa_conv2d_pair``; csrc/conv_ring_pair.h)."""
+    check(load().rsa_conv2d_pair(C.byref(a), C.byref(b), C.c_void_p(stream)), 'rsa_conv2d_pair')
+
+
+def conv_pair_fusable(a: ConvParams, b: ConvParams) -> bool:
+    return bool(load().rsa_conv_pair_fusable(C.byref(a), C.byref(b)))
+
+
+def set_pair_fusion(mode: int) -> None:
+    """Debug / A-B: 1 = ``rsa_conv2d_list`` fuses eligible neighbours, 0 = it launches them one by one, -1 = follow RSA_CONV_PAIR."""
+    load().rsa_debug_set_pair(int(mode))
 
 
 def set_ring_spin_limit(polls: int) -> None:

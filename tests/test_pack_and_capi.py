@@ -56,7 +56,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(L.lib_path())
     for name in declared:
         assert hasattr(lib, name), name
-    assert L.load().rsa_version() == 300
+    assert L.load().rsa_version() == 400
 
 
 def test_conv_params_struct_matches_header_field_order():
