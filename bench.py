@@ -59,6 +59,7 @@ def parse():
     ap.add_argument('--cpu-crop', type=int, default=256)
     ap.add_argument('--halo', type=int, default=32)
     ap.add_argument('--no-power', action='store_true', help='skip the socket-power leg (rocm-smi sampled by a child process started before the GPU is touched)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the compact c3 / c4 legs that the default one-GPU run appends under "secondary"')
     ap.add_argument('--no-kernel-roofline', action='store_true', help='skip the per-kernel replays (profiling runs: keeps the launch mix that of plain forwards)')
     ap.add_argument('--dry-run', action='store_true', help='launcher / rendezvous check without a GPU: ranks meet over gloo, rank 0 prints a stub line')
     ap.add_argument('--io', default='f32', choices=['f32', 'u8'], help='tensors crossing the boundary: fp32 [N,C,H,W] in / out, or uint8 [N,H,W,C] images in / out '
@@ -160,42 +161,70 @@ def measured_traffic() -> dict:
             f'{rec.get("traffic_GB_per_forward", 0):.1f} GB = {rec.get("traffic_over_algorithmic", 0):.2f}x the 258.5 GB layer-wise bf16 model'}  # fmt: skip
 
 
-def kernel_classes(model, reps: int) -> list:
-    """Per-kernel roofline, measured live: every launch descriptor of the model's 1080p plan is replayed alone through the C-ABI
-    between two HIP events on the launch stream (``reps`` launches per distinct layer shape), grouped by the kernel it dispatches to."""
+def kernel_classes(model, reps: int, x=None) -> list:
+    """Per-kernel roofline, measured live and IN THE FRAME: the launch list of the model's plan is replayed in order through the C-ABI, one
+    launch (or one fused pair of launches: what rsa_conv2d_list makes of two fusable neighbours) at a time with a HIP event between
+    consecutive launches on the launch stream, ``reps`` passes; a launch's duration is the time between its two events, so every launch runs
+    in the cache state its predecessor leaves (round 3 replayed each distinct shape alone, back to back with itself, which over-counted
+    the frame by 6 %).  Grouped by the kernel a launch dispatches to; the classes sum to the replayed frame."""
     from resselt_amd.engine import lib as L
 
     from resselt_amd.engine.base import conv_algorithmic_bytes
 
+    if x is not None:
+        keep = model(x)  # fills the plan's buffers; holding the result keeps the last layer's output pointer valid during the replays
+        torch.cuda.synchronize()
     plan = model.last_plan()
     stream = torch.cuda.current_stream().cuda_stream
-    shapes: dict = {}
-    for arr, cins in zip(plan.conv_arrays, plan.conv_cin):
-        for i in range(len(arr)):
+    # (callable, kernel name, flop, algorithmic bytes, products); name None = host-side steps and unpriced layout / copy kernels ("other")
+    launches = []
+    for step in plan.steps:
+        conv = getattr(step, '_rsa_conv', None)
+        if conv is None:
+            meta = getattr(step, '_rsa_meta', None)
+            if meta is None:
+                launches.append((step, None, 0.0, 0.0, 1))
+            else:
+                launches.append((step, meta['kernel'], float(meta['flop']), float(meta['bytes']), meta.get('products', 1)))
+            continue
+        arr, cins = conv
+        i = 0
+        while i < len(arr):
             p = arr[i]
-            # one representative per distinct launch shape: geometry, arithmetic, epilogue shape (activation, residuals, outputs)
-            key = (p.ksize, p.cin_planes, p.cout, p.H, p.W, p.upsample2x, bool(p.out_nchw), p.products, p.in_fmt, p.act, bool(p.res1), bool(p.res2),
-                   bool(p.res1_hi), bool(p.res2_hi), bool(p.out_f32), bool(p.out_lo), cins[i])  # fmt: skip
-            shapes.setdefault(key, [0, arr, i])[0] += 1
-    groups: dict = {}
-    for key, (count, arr, i) in shapes.items():
-        one = (L.ConvParams * 1)(arr[i])
-        L.conv2d_list(one, stream)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            L.conv2d_list(one, stream)
-        e1.record()
+            flop = 2.0 * p.ksize * p.ksize * cins[i] * p.cout * p.H * p.W * p.batch  # the layer's TRUE input channels (a 3-channel first layer occupies a plane of 8)
+            if i + 1 < len(arr) and L.conv_pair_fusable(arr[i], arr[i + 1]):
+                q = arr[i + 1]
+                flop += 2.0 * 9 * cins[i + 1] * q.cout * q.H * q.W * q.batch
+                # every operand once: the common input planes ONCE, both outputs (layer B's last 32 input channels never leave the chip)
+                nbytes = p.cin_planes * 16 * p.batch * p.H * p.W + 2 * ((p.cout + 7) // 8) * 16 * p.batch * p.H * p.W
+                two = (L.ConvParams * 2)(arr[i], arr[i + 1])
+                launches.append((lambda two=two: L.conv2d_list(two, stream), 'rsa::conv_ring_pair (two growth convolutions of a dense block in one launch, one fp16 product)', flop, nbytes, 1))
+                i += 2
+                continue
+            one = (L.ConvParams * 1)(p)
+            launches.append((lambda one=one: L.conv2d_list(one, stream), L.conv_kernel_name(p), flop, conv_algorithmic_bytes(p), p.products))
+            i += 1
+    total_us = [0.0] * len(launches)
+    for rep in range(reps + 1):  # the first pass warms up
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(launches) + 1)]
+        evs[0].record()
+        for k, (fn, *_rest) in enumerate(launches):
+            fn()
+            evs[k + 1].record()
         torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / reps
-        ks, cout, h, w, prod, cin = key[0], key[2], key[3], key[4], key[7], key[-1]
-        flop = 2.0 * ks * ks * cin * cout * h * w * arr[i].batch  # the layer's TRUE input channels (the 3-channel first layer occupies a plane of 8)
-        name = L.conv_kernel_name(arr[i])
+        if rep:
+            for k in range(len(launches)):
+                total_us[k] += evs[k].elapsed_time(evs[k + 1]) * 1e3 / reps
+    other_us = sum(us for (fn, name, *_r), us in zip(launches, total_us) if name is None)
+    timed = [(l, us) for l, us in zip(launches, total_us) if l[1] is not None]
+    launches, total_us = [l for l, _ in timed], [us for _, us in timed]
+    groups: dict = {}
+    for (one, name, flop, nbytes, prod), us in zip(launches, total_us):
         g = groups.setdefault(name, {'kernel': name, 'launches': 0, 'us': 0.0, 'flop': 0.0, 'bytes': 0.0, 'products': prod})
-        g['launches'] += count
-        g['us'] += count * us
-        g['flop'] += count * flop
-        g['bytes'] += count * conv_algorithmic_bytes(arr[i])
+        g['launches'] += 1
+        g['us'] += us
+        g['flop'] += flop
+        g['bytes'] += nbytes
     out = []
     for g in groups.values():
         out.append({
@@ -209,7 +238,11 @@ def kernel_classes(model, reps: int) -> list:
             'bytes_per_launch': round(g['bytes'] / g['launches']),  # every operand once, in the layouts this launch reads and writes
             'gbs': round(g['bytes'] / g['us'] / 1e3, 1),
         })  # fmt: skip
-    return sorted(out, key=lambda c: -c['ms_per_forward'])
+    out.sort(key=lambda c: -c['ms_per_forward'])
+    if other_us > 0.0:
+        out.append({'kernel': 'other (layout conversion, band copies, host-side steps between launches)', 'launches': 0, 'avg_us': 0.0, 'ms_per_forward': round(other_us / 1e3, 3),
+                    'flop_per_launch': 0, 'tflops': 0.0, 'products': 1, 'bytes_per_launch': 0, 'gbs': 0.0})  # fmt: skip
+    return out
 
 
 def dry_run(args, world: int, rank: int) -> None:
@@ -314,20 +347,26 @@ SECONDARY = {
 
 
 def secondary(args):
-    """BASELINE configs[2] (c3) and configs[3] (c4) on ONE GPU, same JSON schema as the headline: roofline of the dominant kernel measured
-    live (every distinct launch of the plan replayed alone between HIP events), the layer-wise HBM fraction, and the CPU oracle beside it."""
-    import resselt_amd
-    from resselt_amd.engine import lib as L
-    from resselt_amd.utils import synth
-
-    cfg = SECONDARY[args.config]
+    """``--config c3 | c4``: one JSON line for BASELINE configs[2] / configs[3]."""
     if args.gpus != 1:
         raise SystemExit(f'--config {args.config} is a one-GPU configuration')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the engine has no CPU path')
-    dev = torch.device('cuda', 0)
-    torch.cuda.set_device(dev)
-    if args.config == 'c3':
+    print(json.dumps(secondary_result(args.config, args, steps=args.steps, warmup=args.warmup)), flush=True)
+
+
+def secondary_result(config: str, args, steps: int, warmup: int, compact: bool = False) -> dict:
+    """BASELINE configs[2] (c3) and configs[3] (c4) on ONE GPU, same JSON schema as the headline: roofline of the dominant kernel measured
+    live (the plan replayed launch by launch between HIP events), the layer-wise HBM fraction, and the CPU oracle beside it.
+    ``compact``: the object the DEFAULT run carries under ``secondary`` (value, ms_per_step, dtype, dominant-kernel roofline, and the
+    max-abs difference against the CPU oracle on a crop of the same synthetic input)."""
+    import resselt_amd
+    from resselt_amd.engine import lib as L
+    from resselt_amd.utils import synth
+
+    cfg = SECONDARY[config]
+    dev = torch.device('cuda', torch.cuda.current_device())
+    if config == 'c3':
         sd = synth.spanplus_state_dict(upscale=4, upsampler='ps', seed=0)
     else:
         sd = synth.swinir_state_dict(embed_dim=240, depths=[6] * 9, num_heads=[8] * 9, upscale=4, upsampler='nearest+conv', resi='3conv', seed=0)
@@ -335,45 +374,28 @@ def secondary(args):
     model.precision = args.precision
     prec = model.resolved_precision()
     x = synth.synth_input(cfg['shape'], seed=0).to(dev).to(cfg['io'])
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(1, warmup)):
         model(x)
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
+    for _ in range(steps):
         y = model(x)
     ev1.record()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
+    dt = (time.perf_counter() - t0) / steps
     L.check_status('bench: timed region')
     aborts = L.ring_aborts()
     if aborts:
         raise SystemExit(f'bench.py: {aborts} ring-schedule hand-offs timed out; the timed forwards are invalid')
     out_px = y.shape[0] * y.shape[2] * y.shape[3]
-    kern_s = ev0.elapsed_time(ev1) / 1e3 / args.steps
-    classes = [] if args.no_kernel_roofline else kernel_classes(model, max(2, min(args.steps, 5)))
-    # the non-convolution launches that carry a price tag (the whole-block Swin kernel): one representative per distinct kernel
-    plan = model.last_plan()
-    seen: dict = {}
-    for meta, fn in ([] if args.no_kernel_roofline else plan.kernel_calls):
-        seen.setdefault(meta['kernel'], [0, meta, fn])[0] += 1
-    for count, meta, fn in seen.values():
-        fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / 3
-        classes.append({'kernel': meta['kernel'], 'launches': count, 'avg_us': round(us, 2), 'ms_per_forward': round(count * us / 1e3, 3),
-                        'flop_per_launch': round(meta['flop']), 'tflops': round(meta['flop'] / us / 1e6, 2), 'products': meta['products'],
-                        'bytes_per_launch': round(meta['bytes']), 'gbs': round(meta['bytes'] / us / 1e3, 1)})  # fmt: skip
-    classes.sort(key=lambda c: -c['ms_per_forward'])
+    kern_s = ev0.elapsed_time(ev1) / 1e3 / steps
+    del y
+    classes = [] if args.no_kernel_roofline else kernel_classes(model, max(2, min(steps, 5)), x)
     flop, hbm = cfg['flop_px'] * out_px, cfg['bytes_px'] * out_px
     res = {
-        'metric': cfg['metric'], 'value': round(out_px / 1e6 / dt, 3), 'unit': 'output megapixels/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'metric': cfg['metric'], 'value': round(out_px / 1e6 / dt, 3), 'unit': 'output megapixels/s', 'n_gpus': 1, 'steps': steps, 'warmup': warmup,
         'ms_per_step': round(dt * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': {'mixed': 'fp16', 'fp16': 'fp16'}.get(prec, 'bf16'), 'data': 'synthetic',
         'config': {'workload': cfg['workload'] + ', synthetic uniform(+-1/sqrt(fan_in)) weights', 'precision': args.precision if args.precision == prec else f'{args.precision} -> {prec}',
@@ -394,11 +416,37 @@ def secondary(args):
                            'frac_mfma': round(fm, 4), 'frac_hbm': round(fh, 4), 'traffic': None, 'avg_launch_us': dom['avg_us'],
                            'launches_per_forward': dom['launches'], 'flop_per_launch': dom['flop_per_launch'], 'bytes_per_launch': dom['bytes_per_launch'],
                            'share_of_frame': round(dom['ms_per_forward'] / (kern_s * 1e3), 3)}  # fmt: skip
-    if not args.no_cpu_baseline:
-        from oracle.span import spanplus_forward
-        from oracle.swinir import swinir_forward
+    from oracle.span import spanplus_forward
+    from oracle.swinir import swinir_forward
 
-        fwd, cshape = (spanplus_forward, (2, 3, 512, 512)) if args.config == 'c3' else (swinir_forward, (1, 3, 128, 128))
+    fwd = spanplus_forward if config == 'c3' else swinir_forward
+    if compact:
+        # parity beside the number: the same model on a crop of the same synthetic input against the CPU oracle (fp32 tensors: the
+        # arithmetic; and tensors of the configuration's dtype: that plus the output rounding of the 16-bit tensor)
+        cshape = (1, 3, 128, 128) if config == 'c3' else (1, 3, 64, 64)
+        xc = synth.synth_input(cfg['shape'], seed=0)[:1, :, : cshape[2], : cshape[3]].contiguous()
+        default_threads = torch.get_num_threads()
+        torch.set_num_threads(8)
+        with torch.no_grad():
+            ref32 = fwd(sd, xc)
+            refio = fwd(sd, xc.to(cfg['io']).float())
+        torch.set_num_threads(default_threads)
+        e32 = (model(xc.to(dev)).float().cpu() - ref32).abs().max().item()
+        eio = (model(xc.to(dev).to(cfg['io'])).float().cpu() - refio).abs().max().item()
+        torch.cuda.synchronize()
+        L.check_status('bench: parity leg')
+        out = {k: res[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype')}
+        out['config'] = res['config']
+        out['roofline'] = {k: res['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'frac_mfma', 'frac_hbm', 'avg_launch_us',
+                                                           'launches_per_forward', 'share_of_frame')} if 'roofline' in res else None  # fmt: skip
+        out['roofline_frame_frac_mfma'] = res['roofline_frame']['frac']
+        out['roofline_hbm_frac'] = res['roofline_hbm']['frac']
+        out['parity'] = {'max_abs_vs_oracle_fp32_tensors': float(f'{e32:.3e}'), f'max_abs_vs_oracle_{str(cfg["io"]).split(".")[-1]}_tensors': float(f'{eio:.3e}'),
+                         'sample': f'{"x".join(map(str, cshape))} crop of the synthetic input, oracle ({fwd.__module__}) fp32 on the CPU'}  # fmt: skip
+        model._invalidate()
+        return out
+    if not args.no_cpu_baseline:
+        cshape = (2, 3, 512, 512) if config == 'c3' else (1, 3, 128, 128)
         xc = synth.synth_input(cshape, seed=0)
         default_threads = torch.get_num_threads()
         torch.set_num_threads(8)
@@ -412,7 +460,7 @@ def secondary(args):
         torch.set_num_threads(default_threads)
         res['cpu_baseline'] = {'value': round(yc.shape[0] * yc.shape[2] * yc.shape[3] / 1e6 / best, 4), 'unit': 'output megapixels/s', 'cores': 8, 'kind': 'port',
                                'sample': f'oracle ({fwd.__module__}) fp32 on a {"x".join(map(str, cshape))} sample of the workload, best of 2, {best:.2f} s, torch {torch.__version__} CPU'}  # fmt: skip
-    print(json.dumps(res), flush=True)
+    return res
 
 
 def main():
@@ -562,9 +610,10 @@ def main():
             classes = [{'kernel': 'all conv launches of one forward (per-kernel replays skipped)', 'launches': n_launch, 'avg_us': round(kern_s / n_launch * 1e6, 2),
                         'ms_per_forward': round(kern_s * 1e3, 3), 'flop_per_launch': round(flop / n_launch), 'tflops': round(achieved_tf, 2)}]  # fmt: skip
         else:
-            classes = kernel_classes(model, max(2, min(args.steps, 5)))
-        dom = max(classes, key=lambda c: c['ms_per_forward'])
-        issued_tf = sum(c['tflops'] * c.get('products', 1) * c['ms_per_forward'] for c in classes) / max(1e-9, sum(c['ms_per_forward'] for c in classes))
+            classes = kernel_classes(model, max(2, min(args.steps, 5)), xt)
+        priced = [c for c in classes if c['launches']]
+        dom = max(priced, key=lambda c: c['ms_per_forward'])
+        issued_tf = sum(c['tflops'] * c.get('products', 1) * c['ms_per_forward'] for c in priced) / max(1e-9, sum(c['ms_per_forward'] for c in priced))
         traffic = measured_traffic() if (prec == 'mixed' and (H, W, args.blocks) == (1080, 1920, 23)) else {'bytes': None, 'note': 'PMC traffic is only collected for the default workload'}
         # which roof the dominant kernel is nearer to: its algorithmic FLOP rate over the dense MFMA peak, or its algorithmic bytes (every
         # operand once, in the layouts it reads and writes) per second over the HBM peak
@@ -651,6 +700,18 @@ def main():
                 torch.cuda.synchronize()
             w1 = time.time()
             res['power'] = sampler.stop(w1 - 2.0, w1)
+        res['roofline_kernels_note'] = ('the launch list of one forward replayed in order, one launch at a time, a HIP event between consecutive launches: '
+                                        f'sum of ms_per_forward = {sum(c["ms_per_forward"] for c in classes):.3f} ms (the replayed frame; forward_ms_1080p is the same list in one host call)')
+        if world == 1 and args.config == 'c2' and not args.no_secondary and (H, W, args.blocks) == (1080, 1920, 23):
+            # BASELINE configs[2] and [3] in the same process, after the headline (its buffers are released first): compact objects
+            model._invalidate()
+            torch.cuda.empty_cache()
+            res['secondary'] = {}
+            for name in ('c3', 'c4'):
+                t_sec = time.perf_counter()
+                res['secondary'][name] = secondary_result(name, args, steps=max(3, min(args.steps, 10)), warmup=2, compact=True)
+                res['secondary'][name]['leg_seconds'] = round(time.perf_counter() - t_sec, 1)
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(sd, args.cpu_crop)
         print(json.dumps(res), flush=True)

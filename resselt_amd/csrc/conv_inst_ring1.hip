@@ -39,9 +39,10 @@ int conv_ring1h_set_dbg(unsigned v);
 int conv_ring2h_set_dbg(unsigned v);
 int conv_ring3h_set_dbg(unsigned v);
 int conv_ring3hx_set_dbg(unsigned v);
+int conv_ringpair_set_dbg(unsigned v);
 }  // namespace rsa
 extern "C" int rsa_debug_ring_flags(unsigned v) {
   if (hipMemcpyToSymbol(HIP_SYMBOL(rsa::g_ring_dbg), &v, sizeof(v)) != hipSuccess) return -1;
-  return rsa::conv_ring2_set_dbg(v) | rsa::conv_ring3_set_dbg(v) | rsa::conv_ring1h_set_dbg(v) | rsa::conv_ring2h_set_dbg(v) | rsa::conv_ring3h_set_dbg(v) | rsa::conv_ring3hx_set_dbg(v);
+  return rsa::conv_ring2_set_dbg(v) | rsa::conv_ring3_set_dbg(v) | rsa::conv_ring1h_set_dbg(v) | rsa::conv_ring2h_set_dbg(v) | rsa::conv_ring3h_set_dbg(v) | rsa::conv_ring3hx_set_dbg(v) | rsa::conv_ringpair_set_dbg(v);
 }
 #endif

@@ -60,5 +60,18 @@ int conv_launch_pair(const rsa_conv_params& a, const rsa_conv_params& b, hipStre
 }
 
 unsigned int conv_ring_pair_aborts() { return ring_aborts_this_unit(); }
+#ifdef RSA_PAIR_STAMPS
+}  // namespace rsa
+extern "C" int rsa_debug_pair_stamps(unsigned long long* out, int n) {  // diagnostic build: copies the stamp table (synchronises) and clears it
+  static unsigned long long zero[256 * 9 * 8];
+  if (n > 256 * 9 * 8) n = 256 * 9 * 8;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rsa::g_pair_stamps), sizeof(unsigned long long) * n) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(rsa::g_pair_stamps), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+namespace rsa {
+#endif
+#ifdef RSA_RING_DEBUG
+int conv_ringpair_set_dbg(unsigned v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_ring_dbg), &v, sizeof(v)) == hipSuccess ? 0 : -1; }
+#endif
 
 }  // namespace rsa

@@ -56,7 +56,25 @@ struct PairParams {
 #define RSA_PAIR_WD 3  // K steps of weight prefetch
 #endif
 #ifndef RSA_PAIR_DEPTH
-#define RSA_PAIR_DEPTH 4  // pixel-tile steps of LDS fragment prefetch
+#define RSA_PAIR_DEPTH 3  // pixel-tile steps of LDS fragment prefetch (3 / 4 / 6: 224 / 235 / 297 us on the conv1+conv2 pair at 1080p, profiles/r04_b_*)
+#endif
+#ifndef RSA_PAIR_PRIO_B
+#define RSA_PAIR_PRIO_B 1  // s_setprio of the layer-B waves (4-7: the younger half of the workgroup, and the longer chain per tile)
+#endif
+#ifndef RSA_PAIR_PRIO_A
+#define RSA_PAIR_PRIO_A 0
+#endif
+
+#ifdef RSA_PAIR_STAMPS
+// diagnostic build only (tools/variant.sh pair_stamps "-DRSA_PAIR_STAMPS"): per-wave cycle totals of the kernel's phases, written to memory no
+// other code reads.  [workgroup][wave 0..8][slot]: 0 total, 1 waiting for ring fills (FULL) / for FREE slots (loader), 2 waiting for the
+// x_A image hand-offs (XFULL / XFREE), 3 epilogue, 4 x_A unit of layer B, 5 tiles
+static __device__ unsigned long long g_pair_stamps[256 * 9 * 8];
+#define PSTAMP() __builtin_amdgcn_s_memtime()
+#define PST_ADD(slot, t0) st[slot] += PSTAMP() - (t0)
+#else
+#define PSTAMP() 0ull
+#define PST_ADD(slot, t0) (void)(t0)
 #endif
 
 struct PairGeo {
@@ -119,6 +137,11 @@ __device__ __forceinline__ void pair_consumer(const PairParams& p, const RingAux
   uint32_t* const f_xfull = flags + 11;
   uint32_t* const f_xfree = flags + 12;
   const int nqa = p.nqa;
+#ifdef RSA_RING_DEBUG
+  const unsigned dbg = __builtin_amdgcn_readfirstlane(g_ring_dbg);
+#endif
+  if (roleB && RSA_PAIR_PRIO_B) __builtin_amdgcn_s_setprio(RSA_PAIR_PRIO_B);
+  if (!roleB && RSA_PAIR_PRIO_A) __builtin_amdgcn_s_setprio(RSA_PAIR_PRIO_A);
   const int r4 = wave & 3;  // group of four rows
   const int li = lane & 15;
   const int lg = lane >> 4;
@@ -137,6 +160,7 @@ __device__ __forceinline__ void pair_consumer(const PairParams& p, const RingAux
   auto load_w = [&](int s) {  // -> wq[WD]
 #pragma unroll
     for (int c = 0; c < CTW; ++c) {
+      if (RING_DBG(4)) continue;
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, woff[c], (uint32_t)s * wstep, 0);
       wq[WD][c] = __builtin_bit_cast(bf16x8, v);
     }
@@ -180,6 +204,10 @@ __device__ __forceinline__ void pair_consumer(const PairParams& p, const RingAux
   int slot = 0;
   uint32_t use = 0;
   uint32_t tcount = 0;  // tiles this workgroup has finished
+#ifdef RSA_PAIR_STAMPS
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_begin = PSTAMP();
+#endif
 
   // One unit of nine K steps over the two 16-channel halves at units bA / bB (RS = their row stride).  RING: the halves are ring slots
   // sA / sB -- wait for their fills, hand them back after their last read.
@@ -189,7 +217,11 @@ __device__ __forceinline__ void pair_consumer(const PairParams& p, const RingAux
     constexpr int NSTEP = KSU * NPT;
     const int uA1 = bA + hsel, uA2 = bA + 2 + hsel * RS, uB1 = bB + hsel, uB2 = bB + 2 + hsel * RS;
     const int uS = (hsel ? bB : bA) + 2 * RS + 2;
-    if (RING) ring_wait(&f_full[sA], needA, f_abort, aux);
+    {
+      const unsigned long long tw = PSTAMP();
+      if (RING) ring_wait(&f_full[sA], needA, f_abort, aux);
+      if (RING) PST_ADD(1, tw);
+    }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
     bf16x8 rh[DEPTH + 1];
@@ -222,7 +254,8 @@ __device__ __forceinline__ void pair_consumer(const PairParams& p, const RingAux
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (i + DEPTH < NSTEP) rh[(i + DEPTH) % (DEPTH + 1)] = *(const bf16x8*)&s_ring[frag(i + DEPTH)];
+      if (i + DEPTH < NSTEP && !RING_DBG(16)) rh[(i + DEPTH) % (DEPTH + 1)] = *(const bf16x8*)&s_ring[frag(i + DEPTH)];
+      if (!RING_DBG(2))
 #pragma unroll
       for (int ct = 0; ct < CTW; ++ct) acc[sp][ct] = mfma16<RSA_PF_F16>(wq[0][ct], rh[i % (DEPTH + 1)], acc[sp][ct]);
       if (i + DEPTH < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -232,7 +265,11 @@ __device__ __forceinline__ void pair_consumer(const PairParams& p, const RingAux
     constexpr int FIRST_B = 4 * NPT - DEPTH;  // the step whose prefetch is the first read of the pairing step (half B)
 #pragma unroll
     for (int i = 0; i < FIRST_B; ++i) step(i);
-    if (RING) ring_wait(&f_full[sB], needB, f_abort, aux);
+    {
+      const unsigned long long tw = PSTAMP();
+      if (RING) ring_wait(&f_full[sB], needB, f_abort, aux);
+      if (RING) PST_ADD(1, tw);
+    }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -261,13 +298,17 @@ __device__ __forceinline__ void pair_consumer(const PairParams& p, const RingAux
     const int col = 16 * (llg & 1) + lli;     // column of this lane's unit inside a 32-pixel row of tiles
     if (!roleB) {
       // ---- A: bias + LeakyReLU, fp16; the 18 x 32 region -> the LDS image (zeros outside the picture), its 16 x 30 interior -> memory ----
+      const unsigned long long tx0 = PSTAMP();
       ring_wait(f_xfree, 4u * tcount, f_abort, aux);  // the B waves have finished with the previous tile's image
+      PST_ADD(2, tx0);
+      const unsigned long long te0 = PSTAMP();
       char* const ob = (char*)p.outa_hi + (p.outa_unit0 + (int64_t)n * p.outa_batch_stride + (int64_t)(y0 - 1) * p.W + (x0 - 1)) * 16;
       const int x = x0 - 1 + col;
       const bool xin = (uint32_t)x < (uint32_t)p.W;
       const bool xst = xin && col >= 1 && col <= G::TWO;
 #pragma unroll
       for (int ct = 0; ct < CTW; ++ct) {
+        if (RING_DBG(8)) break;
         const f32x4 bias = p.bias_a != nullptr ? ((const f32x4*)p.bias_a)[ct * 4 + llg] : (f32x4){0.f, 0.f, 0.f, 0.f};
         const uint32_t pl_off = (uint32_t)(2 * ct + plane_l);
 #pragma unroll
@@ -298,15 +339,22 @@ __device__ __forceinline__ void pair_consumer(const PairParams& p, const RingAux
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the image writes of this wave have landed
       if (lane == 0) __hip_atomic_fetch_add(f_xfull, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      PST_ADD(3, te0);
     } else {
       // ---- B: the last 32 input channels = A's output, out of the LDS image; then bias + LeakyReLU and the 16 x 30 tile -> memory ----
+      const unsigned long long tx0 = PSTAMP();
       ring_wait(f_xfull, 4u * (tcount + 1u), f_abort, aux);
-      run_unit(integral_constant<int, AW>{}, integral_constant<bool, false>{}, nqa, lane_ub, lane_ub + 2 * PSB, 0, 0, 0u, 0u);
+      PST_ADD(2, tx0);
+      const unsigned long long tu0 = PSTAMP();
+      if (!RING_DBG(32)) run_unit(integral_constant<int, AW>{}, integral_constant<bool, false>{}, nqa, lane_ub, lane_ub + 2 * PSB, 0, 0, 0u, 0u);
       if (lane == 0) __hip_atomic_fetch_add(f_xfree, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      PST_ADD(4, tu0);
+      const unsigned long long te0 = PSTAMP();
       char* const ob = (char*)p.outb_hi + (p.outb_unit0 + (int64_t)n * p.outb_batch_stride + (int64_t)y0 * p.W + x0) * 16;
       const bool xst = x0 + col < p.W && col < G::TWO;
 #pragma unroll
       for (int ct = 0; ct < CTW; ++ct) {
+        if (RING_DBG(8)) break;
         const f32x4 bias = p.bias_b != nullptr ? ((const f32x4*)p.bias_b)[ct * 4 + llg] : (f32x4){0.f, 0.f, 0.f, 0.f};
         const uint32_t pl_off = (uint32_t)(2 * ct + plane_l);
 #pragma unroll
@@ -317,6 +365,7 @@ __device__ __forceinline__ void pair_consumer(const PairParams& p, const RingAux
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      PST_ADD(3, te0);
     }
 #pragma unroll
     for (int pt = 0; pt < NPT; ++pt)
@@ -324,6 +373,12 @@ __device__ __forceinline__ void pair_consumer(const PairParams& p, const RingAux
       for (int ct = 0; ct < CTW; ++ct) acc[pt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
     ++tcount;
   }
+#ifdef RSA_PAIR_STAMPS
+  st[0] = PSTAMP() - t_begin;
+  st[5] = tcount;
+  if (lane == 0 && blockIdx.x < 256)
+    for (int i = 0; i < 8; ++i) g_pair_stamps[((int)blockIdx.x * 9 + wave) * 8 + i] = st[i];
+#endif
 }
 
 
@@ -359,6 +414,9 @@ __global__ __launch_bounds__(9 * 64, 3) void conv_ring_pair(const PairParams p, 
 
   if (tid < 4 * G::FLAG_UNITS) flags[tid] = 0;
   __syncthreads();  // the only workgroup barrier of the kernel
+#ifdef RSA_RING_DEBUG
+  const unsigned dbg = __builtin_amdgcn_readfirstlane(g_ring_dbg);
+#endif
 
   if (wave == 8) {
     // =========================== LOADER WAVE ===========================
@@ -390,6 +448,10 @@ __global__ __launch_bounds__(9 * 64, 3) void conv_ring_pair(const PairParams p, 
         pend_slot[i] = -1;
       }
     };
+#ifdef RSA_PAIR_STAMPS
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = PSTAMP();
+#endif
     for (int j = 0; j < ntw; ++j) {
       int n, ty, tx;
       ring_tile_coords(p.tile_order ? num_tiles - 1 - (tile0 + j * NWG) : tile0 + j * NWG, tiles_x, tiles_y, n, ty, tx);
@@ -401,13 +463,16 @@ __global__ __launch_bounds__(9 * 64, 3) void conv_ring_pair(const PairParams p, 
           bool any = false;
 #pragma unroll
           for (int i = 0; i < INFL; ++i) any = any || pend_slot[i] >= 0;
+          const unsigned long long tw = PSTAMP();
           if (any) publish_all();  // the consumers may need these fills to reach the release this wave is about to wait for
           ring_wait(&f_free[slot], NCONS * use, f_abort, aux);
+          PST_ADD(1, tw);
         }
         const int64_t half_unit = tile_unit + (int64_t)(2 * h) * p.in_plane_stride;
         gcptr bh = uniform_ptr((gcptr)p.in_hi + half_unit * 16);
         const uint32_t dst = __builtin_amdgcn_readfirstlane(ring_lds + (uint32_t)slot * (SLOT * 16));
-        if (interior) {
+        if (RING_DBG(1)) {
+        } else if (interior) {
 #pragma unroll
           for (int it = 0; it < G::DMA_IT; ++it) {
             if (it == G::DMA_IT - 1 && lane >= 32) continue;
@@ -427,7 +492,9 @@ __global__ __launch_bounds__(9 * 64, 3) void conv_ring_pair(const PairParams p, 
           }
         }
         if (pend_slot[0] >= 0) {
+          const unsigned long long tw = PSTAMP();
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL * G::DMA_IT) : "memory");
+          PST_ADD(2, tw);  // loader: waiting for an older fill to land
           __hip_atomic_store(&f_full[pend_slot[0]], pend_val[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
 #pragma unroll
@@ -438,6 +505,11 @@ __global__ __launch_bounds__(9 * 64, 3) void conv_ring_pair(const PairParams p, 
       }
     }
     publish_all();
+#ifdef RSA_PAIR_STAMPS
+    st[0] = PSTAMP() - t_begin;
+    if (lane == 0 && blockIdx.x < 256)
+      for (int i = 0; i < 8; ++i) g_pair_stamps[((int)blockIdx.x * 9 + 8) * 8 + i] = st[i];
+#endif
     return;
   }
 

@@ -131,7 +131,12 @@ class Plan:
         self.conv_cin.append(self._pending_cin)
         self._pending_cin = []
         dev = self.device
-        self.steps.append(lambda: L.conv2d_list(arr, ops.current_stream_ptr(dev)))
+
+        def step():
+            L.conv2d_list(arr, ops.current_stream_ptr(dev))
+
+        step._rsa_conv = (arr, self.conv_cin[-1])  # bench.py replays the list launch by launch (in-frame per-kernel timing)
+        self.steps.append(step)
         return arr
 
     def call(self, fn: Callable[[], None], meta: dict | None = None) -> None:
@@ -140,6 +145,10 @@ class Plan:
         self.steps.append(fn)
         if meta is not None:
             self.kernel_calls.append((meta, fn))
+            try:
+                fn._rsa_meta = meta
+            except AttributeError:  # a callable that takes no attributes (functools.partial does; builtins do not): not priced
+                pass
 
     def run(self) -> None:
         self.flush()
@@ -360,20 +369,29 @@ class EngineModule(nn.Module):
         while len(self._plans) > 1 and (len(self._plans) > self._max_plans or sum(e[0].buffer_bytes() for e in self._plans.values()) > self.max_plan_bytes):
             self._drop_plan(next(iter(self._plans)))
         plan, set_input, get_output, graph = entry
+        name = type(self).__name__
         with torch.cuda.device(x.device):
             if not self.use_graph:
                 set_input(x.contiguous())
-                plan.run()
-                # a host-visible word, no synchronisation: raises for a failed ring hand-off of any launch that has completed by now
-                # (at the latest, the next forward or an explicit L.check_status() after a synchronise reports this one's)
-                L.check_status(type(self).__name__)
+                try:
+                    plan.run()
+                finally:
+                    # The failure word of the ring kernels is read (and cleared) exactly once per forward, whether or not the launch list
+                    # raised: a failure reported by an EARLIER forward's kernels makes rsa_conv2d_list refuse to launch, and that refusal
+                    # must not leave the word set for every later call.  A host-visible word, no synchronisation: it reports the hand-offs
+                    # of every launch that has completed by now (``sync_check`` / ``tiling.upscale*`` synchronise first to judge this one).
+                    L.check_status(name)
                 return get_output()
             if graph is None:
                 static_x = x.contiguous().clone()
                 set_input(static_x)  # one eager pass first: lazy initialisation and allocator warm-up must not happen under capture
-                plan.run()
+                try:
+                    plan.run()
+                finally:
+                    L.check_status(name)
                 get_output()
                 torch.cuda.synchronize(x.device)
+                L.check_status(name)  # nothing pending when capture starts (a replay never goes through rsa_conv2d_list's own test)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):  # every C-ABI launch of the plan asks for the CURRENT stream, i.e. the capture stream
                     set_input(static_x)
@@ -383,4 +401,15 @@ class EngineModule(nn.Module):
             g, static_x, static_y = graph
             static_x.copy_(x)
             g.replay()
-            return static_y.clone()
+            y = static_y.clone()
+            L.check_status(name)  # as in the eager path: whatever has completed by now
+            return y
+
+    def sync_check(self, device=None) -> None:
+        """Synchronise ``device`` (default: the parameters' device) and raise if a kernel of any forward issued so far reported a failed
+        hand-off -- the call that makes the result of the LAST forward trustworthy (``forward`` itself never synchronises)."""
+        if device is None:
+            first = next(self.parameters(), None)
+            device = first.device if first is not None else None
+        torch.cuda.synchronize(device)
+        L.check_status(type(self).__name__)

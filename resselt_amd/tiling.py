@@ -84,11 +84,23 @@ def _is_image(x: torch.Tensor) -> bool:
     return x.dtype == torch.uint8
 
 
+def _finish(y: torch.Tensor) -> torch.Tensor:
+    """Last step of every helper that hands an image back to the user: synchronise and ask the engine whether any kernel reported a
+    failed hand-off (``EngineModule.forward`` itself never synchronises, so a failure of the LAST launches would otherwise surface one
+    call late).  A no-op for CPU tensors (the CPU tests drive this module with the oracle)."""
+    if isinstance(y, torch.Tensor) and y.is_cuda:
+        from .engine import lib as L
+
+        torch.cuda.synchronize(y.device)
+        L.check_status('upscale')
+    return y
+
+
 def run_tile(model: Callable[[torch.Tensor], torch.Tensor], x: torch.Tensor, tile: Tile, scale: int) -> torch.Tensor:
     """Upscale one tile (with its halo) and crop the halo off the result (a view of the model's output, not a copy)."""
     img = _is_image(x)
     if tile.y1 <= tile.y0 or tile.x1 <= tile.x0:
-        return x.new_zeros((x.shape[0], 0, 0, 0))
+        return x.new_zeros((x.shape[0], 0, 0, x.shape[3]) if img else (x.shape[0], x.shape[1], 0, 0))
     crop = (x[:, tile.ry0 : tile.ry1, tile.rx0 : tile.rx1] if img else x[:, :, tile.ry0 : tile.ry1, tile.rx0 : tile.rx1]).contiguous()
     y = model(crop)
     oy, ox = (tile.y0 - tile.ry0) * scale, (tile.x0 - tile.rx0) * scale
@@ -96,17 +108,26 @@ def run_tile(model: Callable[[torch.Tensor], torch.Tensor], x: torch.Tensor, til
     return y[:, oy : oy + th * scale, ox : ox + tw * scale] if img else y[:, :, oy : oy + th * scale, ox : ox + tw * scale]
 
 
-def upscale_tiled(model, x: torch.Tensor, scale: int, tile: tuple[int, int], halo: int = 32, align: int = 1) -> torch.Tensor:
-    """Single-device tiling of a large image: bounds the engine's activation buffers (e.g. 8K inputs)."""
-    n, _, h, w = x.shape
+def upscale_tiled(model, x: torch.Tensor, scale: int, tile: tuple[int, int], halo: int = 32, align: int = 1, check: bool = True) -> torch.Tensor:
+    """Single-device tiling of a large image: bounds the engine's activation buffers (e.g. 8K inputs).  ``x``: a float ``[N, C, H, W]``
+    tensor, or a uint8 ``[N, H, W, C]`` image for models with ``supports_u8`` (the layouts ``run_tile`` / ``TileParallel`` take)."""
+    if x.dim() != 4:
+        raise ValueError(f'expected a [N, C, H, W] tensor or a uint8 [N, H, W, C] image, got shape {tuple(x.shape)}')
+    img = _is_image(x)
+    n = x.shape[0]
+    h, w = (x.shape[1], x.shape[2]) if img else (x.shape[2], x.shape[3])
     rows, cols = -(-h // tile[0]), -(-w // tile[1])
     out = None
     for t in plan_tiles(h, w, rows, cols, halo, align):
         y = run_tile(model, x, t, scale)
         if out is None:
-            out = torch.empty((n, y.shape[1], h * scale, w * scale), dtype=y.dtype, device=y.device)
-        out[:, :, t.y0 * scale : t.y1 * scale, t.x0 * scale : t.x1 * scale] = y
-    return out
+            shape = (n, h * scale, w * scale, y.shape[3]) if img else (n, y.shape[1], h * scale, w * scale)
+            out = torch.empty(shape, dtype=y.dtype, device=y.device)
+        if img:
+            out[:, t.y0 * scale : t.y1 * scale, t.x0 * scale : t.x1 * scale] = y
+        else:
+            out[:, :, t.y0 * scale : t.y1 * scale, t.x0 * scale : t.x1 * scale] = y
+    return _finish(out) if check else out
 
 
 def upscale(model, image: torch.Tensor, tile: tuple[int, int] | None = None, halo: int = 32, align: int = 1,
@@ -132,8 +153,8 @@ def upscale(model, image: torch.Tensor, tile: tuple[int, int] | None = None, hal
     if tile is None or (h <= tile[0] and w <= tile[1]):
         y = model(x)
     else:
-        y = upscale_tiled(model, x, scale, tile, halo, align)
-    out = ops.nchw_to_image_u8(y)
+        y = upscale_tiled(model, x, scale, tile, halo, align, check=False)
+    out = _finish(ops.nchw_to_image_u8(y))
     return out[0] if squeeze else out
 
 
@@ -147,15 +168,8 @@ def _upscale_u8(model, image: torch.Tensor, tile, halo: int, align: int, scale) 
     if tile is None or (h <= tile[0] and w <= tile[1]):
         out = model(img)
     else:
-        rows, cols = -(-h // tile[0]), -(-w // tile[1])
-        out = None
-        for t in plan_tiles(h, w, rows, cols, halo, align):
-            y = model(img[:, t.ry0 : t.ry1, t.rx0 : t.rx1].contiguous())
-            if out is None:
-                out = torch.empty((n, h * scale, w * scale, y.shape[3]), dtype=torch.uint8, device=y.device)
-            oy, ox = (t.y0 - t.ry0) * scale, (t.x0 - t.rx0) * scale
-            th, tw = t.shape
-            out[:, t.y0 * scale : t.y1 * scale, t.x0 * scale : t.x1 * scale] = y[:, oy : oy + th * scale, ox : ox + tw * scale]
+        out = upscale_tiled(model, img, scale, tile, halo, align, check=False)
+    out = _finish(out)
     return out[0] if squeeze else out
 
 
@@ -216,7 +230,7 @@ class TileParallel:
                 if full is None:
                     full = torch.empty(full_shape(o.shape[3] if img else o.shape[1]), dtype=o.dtype, device=o.device)
                 place(full, t, o)
-            return full
+            return _finish(full)
 
         rounds = -(-len(tiles) // world)
         # Can the gather of a round land in the result itself?  Channel-interleaved single image, every tile a full-width row band,
@@ -263,7 +277,7 @@ class TileParallel:
                 place(full, t, recv[k, r, :, : th * s, : tw * s] if img else recv[k, r, :, :, : th * s, : tw * s])
         self.last_stats = dict(rounds=rounds, in_place=bool(in_place), bytes_per_round=int(keep[0].numel() * keep[0].element_size()) * world,
                                tile_dtype=str(dtype), overlap=bool(self.overlap))  # fmt: skip
-        return full
+        return _finish(full)
 
     def _out_meta(self, ref, x, img: bool, idle_ranks: bool):
         """(channels, dtype, device) of the output tiles.  Only when there are fewer tiles than ranks can a rank have no

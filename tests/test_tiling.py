@@ -70,6 +70,25 @@ def _u8_input():
     return torch.randint(0, 256, (1, 48, 40, 3), generator=g, dtype=torch.uint8)
 
 
+def test_upscale_tiled_takes_u8_images():
+    """An 8-bit [N, H, W, C] image through the single-device tiler: tiles are planned over (H, W), not over (W, C), and the result
+    equals the whole-image run wherever the halo covers the receptive field (advisor finding, round 3)."""
+    from resselt_amd.tiling import run_tile, Tile
+
+    model, img = _u8_model(), _u8_input()
+    full = model(img)
+    tiled = upscale_tiled(model, img, scale=2, tile=(20, 16), halo=24)
+    assert tiled.shape == full.shape == (1, 96, 80, 3) and tiled.dtype == torch.uint8
+    assert (tiled.int() - full.int()).abs().max().item() <= 1  # rounding of values that differ by 1e-6 at a .5 boundary
+    assert torch.equal(TileParallel(model, 2, halo=24, grid=(3, 3))(img), upscale_tiled(model, img, scale=2, tile=(16, 14), halo=24))
+    # an empty tile keeps the rank and the channel axis of its layout
+    empty = Tile(0, 5, 5, 0, 0, 5, 5, 0, 0)
+    assert run_tile(model, img, empty, 2).shape == (1, 0, 0, 3)
+    assert run_tile(_model(), synth.synth_input((1, 3, 8, 8), seed=1), empty, 2).shape == (1, 3, 0, 0)
+    with pytest.raises(ValueError):
+        upscale_tiled(model, img[0], scale=2, tile=(20, 16))
+
+
 def _u8_worker(rank, world, port, q):
     import torch.distributed as dist
 

@@ -20,7 +20,13 @@ from resselt_amd.engine import ops, tensors  # noqa: E402
 from resselt_amd.engine.tensors import PF_F16  # noqa: E402
 
 dev = torch.device('cuda:0')
+if os.environ.get('RSA_LIB'):
+    _p = os.path.abspath(os.environ['RSA_LIB'])
+    L.lib_path = lambda: _p  # an experiment build (tools/variant.sh)
 lib = L.load()
+# MASKS="0 1 2 ..." on a -DRSA_RING_DEBUG build: runtime ablations of the fused kernel
+#   1 no LDS-DMA fills, 2 no MFMA, 4 no weight loads, 8 no epilogues, 16 no LDS fragment reads, 32 no x_A unit of layer B
+masks = [int(m) for m in os.environ.get('MASKS', '').split()]
 args = [a for a in sys.argv[1:] if not a.startswith('--')]
 configs = [tuple(int(v) for v in a.split(',')) for a in args] or [(64,), (128,)]
 rounds = int(os.environ.get('AB_ROUNDS', 7))
@@ -57,6 +63,14 @@ for cfg in configs:
             t = timed(lambda: L.conv2d_list(arr, stream))
             if r:
                 times[name].append(t)
+    for m in masks:
+        lib.rsa_debug_ring_flags(m)
+        L.set_pair_fusion(1)
+        ts = [timed(lambda: L.conv2d_list(arr, stream)) for _ in range(4)][1:]
+        torch.cuda.synchronize()
+        print(f'   mask {m:2d}: fused med {statistics.median(ts) * 1e3:.1f} min {min(ts) * 1e3:.1f} us  aborts={L.ring_aborts()}', flush=True)
+    if masks:
+        lib.rsa_debug_ring_flags(0)
     L.set_pair_fusion(-1)
     flop = 2.0 * 9 * 32 * (cin + cin + 32) * H * W
     print(f'pair {cin}->32, {cin + 32}->32  {H}x{W}: ' + '  '.join(f'{n}: med {statistics.median(t) * 1e3:.1f} min {min(t) * 1e3:.1f} us ({flop / statistics.median(t) / 1e9:.0f} TF algorithmic)'
