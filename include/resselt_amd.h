@@ -41,6 +41,8 @@ extern "C" {
 #define RSA_E_ARG (-1)       /* null / out-of-range argument */
 #define RSA_E_UNSUPPORTED (-2) /* combination not compiled in */
 #define RSA_E_ALIGN (-3)     /* pointer not 16-byte aligned */
+#define RSA_E_FP16_RANGE (-5) /* rsa_check_status only: rsa_check_finite has seen an infinity or a NaN since the last call (an activation of a
+                                one-product fp16 layer left the format's range, or the input was not finite): rerun with three bf16 products */
 #define RSA_E_INTERNAL (-4)  /* a kernel reported a protocol failure (ring schedule hand-off timed out): results of the launches since the
                                 last rsa_check_status() == RSA_OK are not to be trusted */
 
@@ -172,6 +174,16 @@ int rsa_conv_pair_fusable(const rsa_conv_params* a, const rsa_conv_params* b);
  * every launch that has COMPLETED.  Call it after the stream (or an event behind the forward) has been synchronised to judge that forward.
  * Returns RSA_OK, or RSA_E_INTERNAL once (the word is cleared; rsa_last_error_string says how many hand-offs failed). */
 int rsa_check_status(void);
+
+/* Range guard of the fp16 plane format.  The fp16 epilogues convert with v_cvt_pk_f16_f32, which turns a value beyond +-65504 into an
+ * infinity; the infinity (or the NaN that inf - inf / inf * 0 make of it) then travels with the residual stream of the network to its end --
+ * the reference's `x5 * 0.2 + x` (utilities/block.py:463-465) carries it -- where ONE pass over a small tensor finds it.  This call scans
+ * `count` elements of a plain array (`dtype`: RSA_F32 / RSA_F16 / RSA_BF16; a split-plane buffer is such an array of its 16-bit format) on
+ * `stream` and adds to a host-visible word when it meets a non-finite value; it never synchronises.  rsa_check_status() then returns
+ * RSA_E_FP16_RANGE once (after RSA_E_INTERNAL, which has priority).  The engine runs it behind every forward of a model whose precision
+ * policy has fp16 layers (0.06 % of an RRDBNet 1080p frame) and `precision = 'auto'` answers a hit by re-running in three bf16 products.
+ * (A saturating convert was rejected: it would turn an out-of-range activation into a finite wrong value that no later check can see.) */
+int rsa_check_finite(const void* data, int32_t dtype, int64_t count, void* stream);
 
 /* Bytes of the packed weight blob for a (cout, cin_planes, ksize, products) convolution. */
 int64_t rsa_packed_weight_bytes(int32_t cout, int32_t cin_planes, int32_t ksize, int32_t products);

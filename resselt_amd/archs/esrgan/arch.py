@@ -243,6 +243,10 @@ class RRDBNet(EngineModule):
                 free.extend(taken[:2])
         # trunk conv + ShortcutBlock (block.py:83-91)
         u = plan.planes(n, pf, h, w, with_lo)
+        if mixed:
+            # run-time guard of the fp16 layers: an activation beyond the fp16 range becomes an infinity that `x5 * 0.2 + x` carries through every
+            # later block into this map (block.py:463-465, :340-344), whatever the output dtype; EngineModule scans it behind every forward
+            plan.range_probe = [u.hi]
         plan.conv(ops.conv_params(W[f'model.1.sub.{nb}'], ws[cur_ws], h, w, cin_planes=pf, res1=fea, alpha=1.0, out=u))
         # ---- tail at 2x / 4x resolution (upconv blocks, HR conv, last conv: arch.py:110-126), run in BANDS of low-resolution rows.
         # A 64-channel map at 4x resolution is 8.5 GB per 1080p frame in split planes; three of them made the plan 25 GB.  The tail is

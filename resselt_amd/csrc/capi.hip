@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "resselt_amd.h"
 
@@ -145,6 +147,39 @@ __global__ void planes_to_nchw_kernel(const void* hi, const void* lo, int64_t pl
   }
 }
 
+// rsa_check_finite: one pass over a plain array; a block that sees a NaN or an infinity adds 1 to the host-visible range word
+template <typename T>
+__global__ void check_finite_kernel(const T* x, int64_t n, unsigned int* word) {
+  // 16 bytes per lane and iteration; the exponent field of every element is tested on the raw bits (all ones = infinity or NaN)
+  constexpr int EPV = 16 / sizeof(T);
+  constexpr uint32_t EXP = sizeof(T) == 4 ? 0x7f800000u : (std::is_same<T, _Float16>::value ? 0x7c00u : 0x7f80u);
+  const int64_t nv = n / EPV;
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 v = ((const uint4*)x)[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (sizeof(T) == 4) {
+        bad |= (w[k] & EXP) == EXP;
+      } else {
+        bad |= (w[k] & EXP) == EXP;
+        bad |= ((w[k] >> 16) & EXP) == EXP;
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - nv * EPV)) {  // tail elements
+    const T t = x[nv * EPV + threadIdx.x];
+    uint32_t b = 0;
+    if (sizeof(T) == 4)
+      b = __builtin_bit_cast(uint32_t, *(const float*)&t);
+    else
+      b = *(const uint16_t*)&t;
+    bad |= (b & EXP) == EXP;
+  }
+  if (__syncthreads_or(bad) && threadIdx.x == 0 && word != nullptr) __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 static unsigned grid_for(int64_t total, int block) {
   int64_t g = (total + block - 1) / block;
   if (g > 256 * 32) g = 256 * 32;
@@ -211,6 +246,25 @@ int rsa_conv_pair_fusable(const rsa_conv_params* a, const rsa_conv_params* b) {
 int rsa_debug_set_pair(int32_t mode) {
   rsa::conv_pair_override(mode);
   return RSA_OK;
+}
+
+int rsa_check_finite(const void* data, int32_t dtype, int64_t count, void* stream) {
+  if (data == nullptr || count < 1) return rsa::set_error(RSA_E_ARG, "check_finite: bad argument");
+  if ((uintptr_t)data & 15) return rsa::set_error(RSA_E_ALIGN, "check_finite: data must be 16-byte aligned");
+  unsigned int* word = rsa::range_word();
+  if (word == nullptr) return rsa::set_error(RSA_E_INTERNAL, "check_finite: no host-visible status word (pinned allocation failed)");
+  const int64_t vecs = count / (dtype == RSA_F32 ? 4 : 8);
+  const unsigned grid = rsa::grid_for(vecs > 0 ? vecs : 1, 256 * 4);
+  if (dtype == RSA_F32)
+    hipLaunchKernelGGL(rsa::check_finite_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)data, count, word);
+  else if (dtype == RSA_F16)
+    hipLaunchKernelGGL(rsa::check_finite_kernel<_Float16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)data, count, word);
+  else if (dtype == RSA_BF16)
+    hipLaunchKernelGGL(rsa::check_finite_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16*)data, count, word);
+  else
+    return rsa::set_error(RSA_E_ARG, "check_finite: dtype must be RSA_F32, RSA_F16 or RSA_BF16");
+  const int rc = (int)hipGetLastError();
+  return rc ? rsa::set_error(rc, "check_finite: launch failed") : RSA_OK;
 }
 
 int rsa_conv_cout_tiles(int32_t cout) { return rsa::conv_nct(cout); }

@@ -103,6 +103,7 @@ struct RingAux {
   int spin_limit;
 };
 RingAux ring_aux();  // conv_mfma.hip
+unsigned int* range_word();  // conv_mfma.hip: device pointer of the host-visible word rsa_check_finite adds to (NULL: no pinned memory)
 // host-visible failure word of the ring kernels (conv_mfma.hip): 0 = nothing to report, else RSA_E_INTERNAL with the count in the error string
 int conv_check_status();
 void conv_set_ring_spin_limit(int polls);

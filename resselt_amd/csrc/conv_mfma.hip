@@ -27,11 +27,12 @@ int conv_launch_k1p3_f16(const rsa_conv_params& p, int nct, hipStream_t stream);
 int conv_launch_k1p3(const rsa_conv_params& p, int nct, hipStream_t stream);
 int conv_launch_k1p1(const rsa_conv_params& p, int nct, hipStream_t stream);
 
-// ---- failure word of the ring kernels: one pinned, device-mapped word per process, allocated at the first ring launch ----
+// ---- status words of the library: one pinned, device-mapped block per process, allocated at the first ring launch or range check ----
+//   word 0: hand-offs of the ring kernels that timed out (conv_ring.h)      word 1: non-finite values seen by rsa_check_finite
 static std::atomic<unsigned int*> g_fail_host{nullptr};
 static std::atomic<unsigned int*> g_fail_dev{nullptr};
 static std::atomic<int> g_spin_limit{1 << 18};
-RingAux ring_aux() {
+static unsigned int* status_words_dev() {
   unsigned int* dev = g_fail_dev.load(std::memory_order_acquire);
   if (dev == nullptr) {
     static std::mutex m;
@@ -40,8 +41,10 @@ RingAux ring_aux() {
     if (dev == nullptr) {
       unsigned int* host = nullptr;
       void* d = nullptr;
-      if (hipHostMalloc((void**)&host, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && host != nullptr) {
-        *host = 0u;
+      // (lazily, not at load time: the library must stay loadable, and its symbols checkable, on a host without a GPU; a first launch under
+      //  stream capture would allocate inside the capture -- EngineModule runs one eager pass before it captures)
+      if (hipHostMalloc((void**)&host, 64, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) == hipSuccess && host != nullptr) {
+        host[0] = host[1] = 0u;
         if (hipHostGetDevicePointer(&d, host, 0) == hipSuccess && d != nullptr) {
           g_fail_host.store(host, std::memory_order_release);
           dev = (unsigned int*)d;
@@ -51,17 +54,30 @@ RingAux ring_aux() {
       (void)hipGetLastError();  // without the word the kernels still count into g_ring_aborts (rsa_debug_ring_aborts)
     }
   }
-  return RingAux{dev, g_spin_limit.load(std::memory_order_relaxed)};
+  return dev;
+}
+RingAux ring_aux() { return RingAux{status_words_dev(), g_spin_limit.load(std::memory_order_relaxed)}; }
+unsigned int* range_word() {
+  unsigned int* dev = status_words_dev();
+  return dev == nullptr ? nullptr : dev + 1;
 }
 void conv_set_ring_spin_limit(int polls) { g_spin_limit.store(polls < 1 ? 1 : polls, std::memory_order_relaxed); }
 int conv_check_status() {
   unsigned int* host = g_fail_host.load(std::memory_order_acquire);
   if (host == nullptr) return RSA_OK;
-  const unsigned int n = __atomic_exchange_n(host, 0u, __ATOMIC_ACQ_REL);
-  if (n == 0) return RSA_OK;
-  char msg[160];
-  snprintf(msg, sizeof(msg), "ring schedule: %u hand-off(s) between loader and compute waves timed out; the affected launches produced wrong pixels", n);
-  return set_error(RSA_E_INTERNAL, msg);
+  const unsigned int n = __atomic_exchange_n(&host[0], 0u, __ATOMIC_ACQ_REL);
+  const unsigned int r = __atomic_exchange_n(&host[1], 0u, __ATOMIC_ACQ_REL);
+  char msg[200];
+  if (n != 0) {
+    snprintf(msg, sizeof(msg), "ring schedule: %u hand-off(s) between loader and compute waves timed out; the affected launches produced wrong pixels", n);
+    return set_error(RSA_E_INTERNAL, msg);
+  }
+  if (r != 0) {
+    snprintf(msg, sizeof(msg), "fp16 range: %u block(s) of a checked tensor hold non-finite values (an activation left the fp16 range of a one-product layer, or the "
+                               "input was not finite); run the model with precision 'bf16x3'", r);
+    return set_error(RSA_E_FP16_RANGE, msg);
+  }
+  return RSA_OK;
 }
 static bool conv_failure_pending() {
   unsigned int* host = g_fail_host.load(std::memory_order_acquire);

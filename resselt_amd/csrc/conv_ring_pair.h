@@ -96,9 +96,10 @@ struct PairGeo {
   static_assert(LDS_UNITS * 16 <= 160 * 1024, "LDS");
 };
 
-// (a, b) -> packed fp16 pair, saturated to the format's range (a value beyond +-65504 would round to infinity)
-__device__ __forceinline__ uint32_t pack_f16_sat(float a, float b) {
-  const f16x2 h = {(_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
+// (a, b) -> packed fp16 pair (RNE; a value beyond +-65504 becomes an infinity, as in every fp16 epilogue of the library: it then travels
+// with the residual stream to the end of the network, where rsa_check_finite finds it -- see include/resselt_amd.h)
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+  const f16x2 h = {(_Float16)a, (_Float16)b};
   return __builtin_bit_cast(uint32_t, h);
 }
 
@@ -113,8 +114,8 @@ __device__ __forceinline__ uint4 pair_unit_f16(const f32x4 a, const f32x4 b, con
     va[r] = fmaxf(va[r], va[r] * slope);
     vb[r] = fmaxf(vb[r], vb[r] * slope);
   }
-  const uint32_t a0 = pack_f16_sat(va[0], va[1]), a1 = pack_f16_sat(va[2], va[3]);
-  const uint32_t b0 = pack_f16_sat(vb[0], vb[1]), b1 = pack_f16_sat(vb[2], vb[3]);
+  const uint32_t a0 = pack_f16(va[0], va[1]), a1 = pack_f16(va[2], va[3]);
+  const uint32_t b0 = pack_f16(vb[0], vb[1]), b1 = pack_f16(vb[2], vb[3]);
   const u32x2 h0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
   const u32x2 h1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
   return make_uint4(h0.x, h1.x, h0.y, h1.y);

@@ -359,6 +359,7 @@ class EngineModule(nn.Module):
         packed = self._weights(x.device)
         key = (shape, x.dtype, str(x.device), self.resolved_precision())
         entry = self._plans.pop(key, None)
+        new_plan = entry is None
         if entry is None:
             plan = Plan(x.device, self.products.fmt)
             set_input, get_output = self._build_plan(plan, packed, shape, x.dtype, self.products)
@@ -370,18 +371,38 @@ class EngineModule(nn.Module):
             self._drop_plan(next(iter(self._plans)))
         plan, set_input, get_output, graph = entry
         name = type(self).__name__
+        guard = self._fp16_guard()  # the resolved policy has fp16 layers: scan for non-finite values behind every forward
+        auto = self.precision == 'auto'
         with torch.cuda.device(x.device):
             if not self.use_graph:
                 set_input(x.contiguous())
+                stale = None
                 try:
                     plan.run()
                 finally:
-                    # The failure word of the ring kernels is read (and cleared) exactly once per forward, whether or not the launch list
+                    # The status words of the library are read (and cleared) exactly once per forward, whether or not the launch list
                     # raised: a failure reported by an EARLIER forward's kernels makes rsa_conv2d_list refuse to launch, and that refusal
-                    # must not leave the word set for every later call.  A host-visible word, no synchronisation: it reports the hand-offs
-                    # of every launch that has completed by now (``sync_check`` / ``tiling.upscale*`` synchronise first to judge this one).
-                    L.check_status(name)
-                return get_output()
+                    # must not leave the word set for every later call.  Host-visible words, no synchronisation: they report every launch
+                    # that has completed by now (``sync_check`` / ``tiling.upscale*`` synchronise first to judge this forward).
+                    try:
+                        L.check_status(name)
+                    except L.Fp16RangeError as e:
+                        stale = e  # an EARLIER forward's range check (this one's kernels are still in flight)
+                y = get_output()
+                if stale is not None:
+                    if not auto:
+                        raise stale
+                    return self._fp16_fallback(x, shape, 'an earlier forward produced non-finite values in its fp16 layers (its result was invalid)')
+                if guard:
+                    self._range_probe(plan, y)
+                    if auto and new_plan:
+                        # the first forward of a plan under 'auto' is judged before it is returned: one synchronisation per input signature
+                        torch.cuda.synchronize(x.device)
+                        try:
+                            L.check_status(name)
+                        except L.Fp16RangeError:
+                            return self._fp16_fallback(x, shape, 'activations left the fp16 range of the one-product layers')
+                return y
             if graph is None:
                 static_x = x.contiguous().clone()
                 set_input(static_x)  # one eager pass first: lazy initialisation and allocator warm-up must not happen under capture
@@ -389,21 +410,65 @@ class EngineModule(nn.Module):
                     plan.run()
                 finally:
                     L.check_status(name)
-                get_output()
+                y0 = get_output()
+                if guard:
+                    self._range_probe(plan, y0)
                 torch.cuda.synchronize(x.device)
-                L.check_status(name)  # nothing pending when capture starts (a replay never goes through rsa_conv2d_list's own test)
+                try:
+                    L.check_status(name)  # nothing pending when capture starts (a replay never goes through rsa_conv2d_list's own test)
+                except L.Fp16RangeError:
+                    if not auto:
+                        raise
+                    return self._fp16_fallback(x, shape, 'activations left the fp16 range of the one-product layers')
+                del y0
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):  # every C-ABI launch of the plan asks for the CURRENT stream, i.e. the capture stream
                     set_input(static_x)
                     plan.run()
                     static_y = get_output()
+                    if guard:
+                        self._range_probe(plan, static_y)
                 graph = entry[3] = (g, static_x, static_y)
             g, static_x, static_y = graph
             static_x.copy_(x)
             g.replay()
             y = static_y.clone()
-            L.check_status(name)  # as in the eager path: whatever has completed by now
+            try:
+                L.check_status(name)  # as in the eager path: whatever has completed by now
+            except L.Fp16RangeError as e:
+                if not auto:
+                    raise
+                return self._fp16_fallback(x, shape, str(e))
             return y
+
+    # -- run-time guard of the fp16 precision policies --
+    def _fp16_guard(self) -> bool:
+        """Whether the resolved precision runs layers on fp16 planes (then every forward is followed by ``rsa_check_finite``)."""
+        p = self.products
+        return p.name in ('mixed', 'fp16') or p.fmt == PF_F16
+
+    def _range_probe(self, plan: 'Plan', y: torch.Tensor) -> None:
+        """Scan for non-finite values where an fp16 overflow of this forward must show: the tensors a plan builder named
+        (``plan.range_probe``: e.g. RRDBNet's trunk output, which every residual dense block feeds), else the output itself."""
+        stream = ops.current_stream_ptr(y.device)
+        probes = getattr(plan, 'range_probe', None)
+        if probes:
+            for t in probes:
+                L.check_finite(t, stream)
+        elif y.is_floating_point():
+            L.check_finite(y if y.is_contiguous() else y.contiguous(), stream)
+
+    def _fp16_fallback(self, x: torch.Tensor, shape, why: str) -> torch.Tensor:
+        """'auto' only: give up the fp16 policy for this module (until its weights change), say so, and run this input in three bf16 products."""
+        import warnings
+
+        warnings.warn(f'{type(self).__name__}: {why}; precision "auto" falls back to "bf16x3" (set model.precision = "bf16x3" to skip the attempt)',
+                      RuntimeWarning, stacklevel=4)  # fmt: skip
+        self._fp16_refused = True
+        self._packed = {}
+        for key in list(self._plans):
+            self._drop_plan(key)
+        return self._forward_locked(x, shape)
 
     def sync_check(self, device=None) -> None:
         """Synchronise ``device`` (default: the parameters' device) and raise if a kernel of any forward issued so far reported a failed

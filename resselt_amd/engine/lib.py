@@ -413,6 +413,7 @@ EXPORTS = (
     'rsa_pack_weights',
     'rsa_conv_kernel_name',
     'rsa_check_status',
+    'rsa_check_finite',
     'rsa_debug_ring_aborts',
     'rsa_debug_set_ring_spin_limit',
     'rsa_debug_set_ring',
@@ -519,6 +520,8 @@ def load() -> C.CDLL:
     lib.rsa_conv_pair_fusable.restype = C.c_int
     lib.rsa_debug_set_ring_spin_limit.argtypes = [C.c_int32]
     lib.rsa_debug_set_ring_spin_limit.restype = C.c_int
+    lib.rsa_check_finite.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
+    lib.rsa_check_finite.restype = C.c_int
     lib.rsa_check_status.argtypes = []
     lib.rsa_check_status.restype = C.c_int
     lib.rsa_nchw_to_planes.argtypes = [
@@ -574,10 +577,30 @@ def load() -> C.CDLL:
     return lib
 
 
+E_FP16_RANGE = -5  # RSA_E_FP16_RANGE
+
+
+class Fp16RangeError(RuntimeError):
+    """``rsa_check_status`` after ``rsa_check_finite`` met an infinity or a NaN: an activation of a one-product fp16 layer left the
+    format's range (or the input was not finite).  ``precision = 'auto'`` answers it by re-running in three bf16 products."""
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().rsa_last_error_string()
-        raise RuntimeError(f'{what} failed (status {rc}): {msg.decode() if msg else "?"}')
+        cls = Fp16RangeError if rc == E_FP16_RANGE else RuntimeError
+        raise cls(f'{what} failed (status {rc}): {msg.decode() if msg else "?"}')
+
+
+def check_finite(t, stream: int) -> None:
+    """Scan a plain float tensor (or the hi / lo storage of a split-plane buffer) for non-finite values (``rsa_check_finite``; asynchronous:
+    ``check_status`` raises ``Fp16RangeError`` once the launch has completed)."""
+    import torch
+
+    dt = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}[t.dtype]
+    if not t.is_contiguous():
+        raise ValueError('check_finite: the tensor must be contiguous')
+    check(load().rsa_check_finite(t.data_ptr(), dt, t.numel(), C.c_void_p(stream)), 'rsa_check_finite')
 
 
 def conv2d_list(params: 'C.Array[ConvParams] | list[ConvParams]', stream: int) -> None:
