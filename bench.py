@@ -435,7 +435,7 @@ def secondary_result(config: str, args, steps: int, warmup: int, compact: bool =
         eio = (model(xc.to(dev).to(cfg['io'])).float().cpu() - refio).abs().max().item()
         torch.cuda.synchronize()
         L.check_status('bench: parity leg')
-        out = {k: res[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype')}
+        out = {k: res[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'event_ms_per_step', 'steps', 'warmup', 'dtype')}
         out['config'] = res['config']
         out['roofline'] = {k: res['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'frac_mfma', 'frac_hbm', 'avg_launch_us',
                                                            'launches_per_forward', 'share_of_frame')} if 'roofline' in res else None  # fmt: skip
@@ -709,7 +709,7 @@ def main():
             res['secondary'] = {}
             for name in ('c3', 'c4'):
                 t_sec = time.perf_counter()
-                res['secondary'][name] = secondary_result(name, args, steps=max(3, min(args.steps, 10)), warmup=2, compact=True)
+                res['secondary'][name] = secondary_result(name, args, steps=max(3, min(args.steps, 10)), warmup=3, compact=True)
                 res['secondary'][name]['leg_seconds'] = round(time.perf_counter() - t_sec, 1)
                 torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:

@@ -37,6 +37,7 @@ __device__ __forceinline__ float ld_as_float(const void* p, int64_t i) {
 typedef __attribute__((ext_vector_type(8))) uint16_t u16x8;
 __device__ __forceinline__ void split_elem(float v, int fmt, uint16_t& hi, uint16_t& lo) {  // (hi, lo) halves of plane format fmt
   if (fmt == RSA_PF_F16) {
+    asm("" : "+v"(v));  // opaque: see conv_common.h, split2
     const _Float16 h = (_Float16)v;
     hi = __builtin_bit_cast(uint16_t, h);
     lo = __builtin_bit_cast(uint16_t, (_Float16)(v - (float)h));

@@ -59,6 +59,16 @@ inline bool conv_ring_em1_eligible(const rsa_conv_params& p) {
          p.out_lo == nullptr && p.res1 == nullptr && p.res2 == nullptr && p.res1_hi == nullptr && p.res2_hi == nullptr && (p.cout & 15) == 0 &&
          (p.act == RSA_ACT_NONE || (p.act == RSA_ACT_LRELU && p.act_param >= 0.f && p.act_param <= 1.f));
 }
+// The re-parameterised 3x3 layers of the SPAN family in the one-product fp16 mode (conv_ring.h, XRES 3): three cout tiles, at most three
+// 16-channel half chunks (the 45 KB weight blob lives in LDS), fp16 plane output, Mish / SiLU / SPAB gate (shortcut as fp16 planes) / LeakyReLU /
+// no activation, nothing else in the epilogue.  RSA_RING_XRES=0 switches the form off.
+inline bool conv_ring_span_eligible(const rsa_conv_params& p) {
+  const bool gate = p.act == RSA_ACT_SPAB_GATE;
+  return p.ksize == 3 && p.products == 1 && p.in_fmt == RSA_PF_F16 && p.out_fmt == RSA_PF_F16 && !p.upsample2x && p.cout == 48 && (p.cin_planes & 3) != 0 &&
+         p.cin_planes <= 6 && p.out_nchw == nullptr && p.out_f32 == nullptr && p.out_hi != nullptr && p.res1 == nullptr && p.res2 == nullptr && p.res2_hi == nullptr &&
+         (gate ? (p.res1_hi != nullptr && p.res_fmt == RSA_PF_F16) : p.res1_hi == nullptr) &&
+         (gate || p.act == RSA_ACT_MISH || p.act == RSA_ACT_SILU || p.act == RSA_ACT_NONE || (p.act == RSA_ACT_LRELU && p.act_param >= 0.f && p.act_param <= 1.f));
+}
 // Nearest x2 upsampling + 3x3 as four 2x2 phase convolutions on the source map (conv_ring_up.h): 64 -> 64 channels, LeakyReLU / none,
 // split-plane output only -- the upconv layers of RRDBNet and of SwinIR's nearest+conv head.  RSA_CONV_UP2=0 switches it off (A/B runs).
 bool conv_up2_enabled();

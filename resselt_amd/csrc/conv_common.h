@@ -113,6 +113,11 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 template <int FMT = 0>
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
   if constexpr (FMT == RSA_PF_F16) {
+    // The values are made opaque first: with a = x * y still visible, the compiler fuses the conversion of the residual into
+    // v_fma_mix*_f16 (x * y - hi rounded once from the exact product) while hi itself is v_cvt_pk_f16_f32 of the f32 product -- the two
+    // roundings of x * y can differ by an fp16 ulp, and hi + lo is then off by that ulp instead of being a 22-bit value (seen on the
+    // Mish / SiLU / gate epilogues: 2.4e-4 on single elements).
+    asm("" : "+v"(a), "+v"(b));
     const f16x2 h = {(_Float16)a, (_Float16)b};
     hi = __builtin_bit_cast(uint32_t, h);
     const f16x2 l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
@@ -215,12 +220,16 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
                                               int x_ps = 0, int x_iw = 0) {
   constexpr int RPW = NPT / 2;
   constexpr bool G = EM == 0;
+  // EM 4 (conv_ring.h XRES 3: the re-parameterised layers of the SPAN family): ONE activation class AC (Mish / SiLU / SPAB gate / linear),
+  // plane output in format PF (hi, and lo where the descriptor has it), the gate's shortcut as plane residual 1 (hi, and lo where it has
+  // it); no f32 map, no second residual, no PReLU, whole cout tiles
+  constexpr bool S = EM == 4;
   const bool R1F = G && p.res1 != nullptr, R2F = G && p.res2 != nullptr;                          // residuals as f32 maps
-  const bool R1P = G ? p.res1_hi != nullptr : EM >= 2, R2P = G ? p.res2_hi != nullptr : EM == 3;  // as planes
-  const bool R1L = G ? p.res1_lo != nullptr : true, R2L = G ? p.res2_lo != nullptr : true;       // ... with lo planes
+  const bool R1P = G ? p.res1_hi != nullptr : (S ? AC == AC_GATE : EM >= 2), R2P = G ? p.res2_hi != nullptr : EM == 3;  // as planes
+  const bool R1L = (G || S) ? p.res1_lo != nullptr : true, R2L = G ? p.res2_lo != nullptr : true;       // ... with lo planes
   const bool OF32 = G && p.out_f32 != nullptr;
-  const bool OHI = G ? p.out_hi != nullptr : true, OLO = G ? p.out_lo != nullptr : !(EM == 1 && PF == RSA_PF_F16);
-  static_assert(EM >= 0 && EM <= 3, "epilogue shape");
+  const bool OHI = G ? p.out_hi != nullptr : true, OLO = (G || S) ? p.out_lo != nullptr : !(EM == 1 && PF == RSA_PF_F16);
+  static_assert(EM >= 0 && EM <= 4, "epilogue shape");
   const bool OF16 = G ? p.out_fmt == RSA_PF_F16 : PF == RSA_PF_F16;  // plane format of the outputs / of the plane residuals
   const bool RF16 = G ? p.res_fmt == RSA_PF_F16 : PF == RSA_PF_F16;
   const bool PRELU = G && p.act == RSA_ACT_PRELU;
@@ -343,8 +352,8 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
       }
     }
   };
-  if (OUTK == 0 && EM == 0) fetch_res(0, 0);
-  if (OUTK == 0 && EM >= 2) {
+  if (OUTK == 0 && (EM == 0 || (S && AC == AC_GATE))) fetch_res(0, 0);
+  if (OUTK == 0 && (EM == 2 || EM == 3)) {
 #pragma unroll
     for (int s = 0; s < PD && s < NSTEPS_E; ++s) fetch_raw(s);
   }
@@ -377,7 +386,7 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
       bool ok[2];
       f32x4 cr1[2], cr2[2];
       if (OUTK == 0) {
-        if (EM >= 2) {
+        if (EM == 2 || EM == 3) {
           const int s = ct * RPW + pp;
           if (s + PD < NSTEPS_E) fetch_raw(s + PD);
 #pragma unroll
@@ -399,7 +408,7 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
             cr2[e] = nr2[e];
           }
         }
-        if (EM != 0) {
+        if (EM != 0 && !(S && AC == AC_GATE)) {
         } else if (pp + 1 < RPW)
           fetch_res(ct, pp + 1);
         else if (ct + 1 < CTW)
@@ -423,7 +432,7 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
           } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              if (G)
+              if (G || (S && AC != AC_LINEAR))
                 v[e][r] = act_apply<AC>(v[e][r], p.act, PRELU ? slope[r] : p.act_param);
               else
                 v[e][r] = fmaxf(v[e][r], v[e][r] * lin_slope);  // none / LeakyReLU with a slope in [0, 1]: two instructions per value

@@ -15,6 +15,7 @@ unsigned int conv_ring1h_aborts();
 unsigned int conv_ring2h_aborts();
 unsigned int conv_ring3h_aborts();
 unsigned int conv_ring3hx_aborts();
+unsigned int conv_ring3hs_aborts();
 
 int conv_launch_ring(const rsa_conv_params& p, hipStream_t stream) {
   if (p.w_layout == RSA_WL_UPPHASE) return conv_launch_ring_up2(p, stream);
@@ -27,7 +28,7 @@ int conv_launch_ring(const rsa_conv_params& p, hipStream_t stream) {
 
 unsigned int conv_ring_aborts() {
   return ring_aborts_this_unit() + conv_ring2_aborts() + conv_ring3_aborts() + conv_ring_up2_aborts() + conv_ring1h_aborts() + conv_ring2h_aborts() + conv_ring3h_aborts() +
-         conv_ring3hx_aborts() + conv_ring_pair_aborts();
+         conv_ring3hx_aborts() + conv_ring3hs_aborts() + conv_ring_pair_aborts();
 }
 }  // namespace rsa
 
@@ -40,9 +41,10 @@ int conv_ring2h_set_dbg(unsigned v);
 int conv_ring3h_set_dbg(unsigned v);
 int conv_ring3hx_set_dbg(unsigned v);
 int conv_ringpair_set_dbg(unsigned v);
+int conv_ring3hs_set_dbg(unsigned v);
 }  // namespace rsa
 extern "C" int rsa_debug_ring_flags(unsigned v) {
   if (hipMemcpyToSymbol(HIP_SYMBOL(rsa::g_ring_dbg), &v, sizeof(v)) != hipSuccess) return -1;
-  return rsa::conv_ring2_set_dbg(v) | rsa::conv_ring3_set_dbg(v) | rsa::conv_ring1h_set_dbg(v) | rsa::conv_ring2h_set_dbg(v) | rsa::conv_ring3h_set_dbg(v) | rsa::conv_ring3hx_set_dbg(v) | rsa::conv_ringpair_set_dbg(v);
+  return rsa::conv_ring2_set_dbg(v) | rsa::conv_ring3_set_dbg(v) | rsa::conv_ring1h_set_dbg(v) | rsa::conv_ring2h_set_dbg(v) | rsa::conv_ring3h_set_dbg(v) | rsa::conv_ring3hx_set_dbg(v) | rsa::conv_ringpair_set_dbg(v) | rsa::conv_ring3hs_set_dbg(v);
 }
 #endif

@@ -115,6 +115,7 @@ const char* conv_kernel_name(const rsa_conv_params& p) {
   if (p.w_layout != RSA_WL_TAPS) {
     const int ct = (p.cout + 15) >> 4;
     if (p.products == 1) {
+      if (ct == 3 && conv_ring_xres_enabled() && conv_ring_span_eligible(p)) return "rsa::conv_ring<3,0,0,HM,f16,1,XRES 3> (SPAN-family 48-channel layer, one fp16 product, weights resident in LDS, direct epilogue)";
       if (ct == 4 && conv_ring_xres_enabled() && conv_ring_xres_eligible(p)) return "rsa::conv_ring<1,0,0,0,f16,1,XRES> (conv5 of a dense block, one fp16 product, residual hi halves from the ring)";
       return ct == 2 ? "rsa::conv_ring<2,0,0,0,f16,1> (Cout<=32, one fp16 product)" : ct == 3 ? (p.out_nchw != nullptr ? "rsa::conv_ring<3,0,1,HM,f16,1> (Cout 33..48, final store, one fp16 product)" : "rsa::conv_ring<3,0,0,HM,f16,1> (Cout 33..48, one fp16 product)") : "rsa::conv_ring<1,0,0,0,f16,1> (Cout 49..64, one fp16 product)";
     }

@@ -76,17 +76,20 @@ typedef const __attribute__((address_space(1))) char* gcptr;
 #define RSA_RING_DEPTH1 4  // pixel-tile steps of LDS fragment prefetch (3, 4, 5: +-0.1 %, profiles/r03_q_*)
 #endif
 
-template <int PROD>
+// WL 1 (XRES 3): the layer's whole weight blob lives in LDS behind the ring (the 48 -> 48 layers of the SPAN family: 45 KB), so the ring has
+// four slots instead of eight and the loader keeps one fill in flight behind the one it publishes
+template <int PROD, int WL = 0>
 struct RingGeoP {
   static constexpr int TH = 16, TW = 32, IH = 18, IW = 34;
   static constexpr int PS = 624;             // plane stride in units (IH*IW = 612 rounded up to 0 mod 16)
   static constexpr int HALF = 2 * PS;        // units of one precision of a slot (2 planes)
   static constexpr int NHL = PROD == 3 ? 2 : 1;
   static constexpr int SLOT = NHL * HALF;    // units per slot: [hi p0][hi p1]([lo p0][lo p1])
-  static constexpr int NSLOT = PROD == 3 ? 4 : 8;
+  static constexpr int NSLOT = (PROD == 3 || WL) ? 4 : 8;
   static constexpr int DMA_IT = (HALF + 63) / 64;  // 20 LDS-DMA instructions per precision; the last one covers 32 units
   static constexpr int DPF = NHL * DMA_IT;   // LDS-DMA instructions per fill
-  static constexpr int INFL = PROD == 3 ? 1 : RSA_RING_INFL1;  // fills left in flight behind the one being published (INFL * DPF <= 63: vmcnt)
+  static constexpr int INFL = (PROD == 3 || WL) ? 1 : RSA_RING_INFL1;  // fills left in flight behind the one being published (INFL * DPF <= 63: vmcnt)
+  static constexpr int WL_FRAGS = WL ? 45 : 0;  // 1 KiB weight fragments resident in LDS (15 K steps x 3 cout tiles)
   static constexpr int BAND = 4;             // tile rows per band of the tile order
   static constexpr int FLAG_UNITS = 5;       // uint4s behind the ring: FULL[8], FREE[8], abort
 };
@@ -152,17 +155,25 @@ __device__ __forceinline__ void dma16_v(uint32_t lds_addr, gcptr vaddr) {
 // its own input): the K loop walks the 32-channel chunks from the LAST to the first, so x's four half chunks are the last fills of a tile;
 // their slots are not handed back until the epilogue has read the residual's hi halves from them (conv_common.h, XL) -- 128 B per pixel that
 // are not fetched from memory a second time.  The loader runs ahead into the other four slots meanwhile.
-template <int SHAPE, int UP, int OUTK, int HM = 0, int FMT = 0, int PROD = 3, int XRES = 0>
+// XRES 3 (SHAPE 3, half mode, one fp16 product, at most three half chunks: the re-parameterised 48 -> 48 layers of SPAN / SPANPlus / SpanPP,
+// archs/spanplus/arch.py:94-130): the weight blob (45 KB) is copied into LDS once per workgroup and every K step reads its fragments from
+// there -- a wave of this shape owns three cout tiles of only four pixel tiles, so its weight stream from L2 was 256 B per matrix
+// instruction, 2.3 x that of the RRDBNet shapes -- and the epilogue is instantiated for ONE activation class XAC (Mish / SiLU / SPAB gate /
+// linear) with its shape folded (conv_common.h, EM 4) instead of going through the generic dispatch (141 spilled scalar registers, 64 B of scratch).
+template <int SHAPE, int UP, int OUTK, int HM = 0, int FMT = 0, int PROD = 3, int XRES = 0, int XAC = 0>
 __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(const rsa_conv_params p, const RingAux aux) {
   static_assert(XRES != 1 || (SHAPE == 1 && PROD == 1 && HM == 0 && UP == 0 && OUTK == 0), "XRES 1: conv5 of a residual dense block only");
   static_assert(XRES != 2 || (PROD == 1 && FMT == RSA_PF_F16 && OUTK == 0), "XRES 2: one fp16 product, hi-only plane output");
+  static_assert(XRES != 3 || (SHAPE == 3 && PROD == 1 && FMT == RSA_PF_F16 && HM == 1 && UP == 0 && OUTK == 0), "XRES 3: the 48-channel SPAN-family layers");
+  constexpr bool WL = XRES == 3;
   constexpr bool XR = XRES == 1;  // (XRES 2: the growth convolutions of a dense block -- hi-only fp16 plane output, LeakyReLU / none, nothing else:
                                   //  the kernel calls that one epilogue shape directly; without the generic dispatch and its dozen descriptor
                                   //  tests it keeps 40 fewer lane registers and 140 fewer scalar registers in scratch)
-  using R = RingGeoP<PROD>;
+  using R = RingGeoP<PROD, WL>;
   constexpr int STREAMS = SHAPE == 2 ? 2 : 1;
   constexpr int TH = R::TH, TW = R::TW, IH = R::IH, IW = R::IW, PS = R::PS, HALF = R::HALF, SLOT = R::SLOT, NSLOT = R::NSLOT;
   constexpr int NHL = R::NHL, INFL = R::INFL;
+  constexpr int WBASE = NSLOT * SLOT + R::FLAG_UNITS;  // WL: first unit of the resident weight blob
   constexpr int NCT = SHAPE == 2 ? 2 : (SHAPE == 1 ? 4 : 3);  // cout tiles of the layer handled by one workgroup
   constexpr int CTW = SHAPE == 3 ? 3 : 2;       // cout tiles per wave
   constexpr int NPT = SHAPE == 3 ? 4 : 8;       // pixel tiles per wave (RPW rows x 2 halves)
@@ -171,7 +182,7 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
   constexpr int SPS = NSLOT / STREAMS;          // slots per stream (a power of two)
 
   // ring + flags in ONE shared array (a second __shared__ object can make hipcc drain vmcnt before LDS reads)
-  __shared__ uint4 s_ring[NSLOT * SLOT + R::FLAG_UNITS];
+  __shared__ uint4 s_ring[NSLOT * SLOT + R::FLAG_UNITS + R::WL_FRAGS * 64];
   uint32_t* const flags = (uint32_t*)&s_ring[NSLOT * SLOT];  // [0..7] FULL, [8..15] FREE, [16] abort
   uint32_t* const f_full = flags;
   uint32_t* const f_free = flags + 8;
@@ -194,6 +205,10 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
   const int ntw = (num_tiles - tile0 + NWG - 1) / NWG;  // tiles of this workgroup: tile0 + j*NWG
 
   if (tid < 4 * R::FLAG_UNITS) flags[tid] = 0;
+  if (WL) {  // the layer's weight blob -> LDS, once per workgroup (the launcher has checked that it fits)
+    const int wunits = nq * 5 * ct_total * 64;
+    for (int i = tid; i < wunits; i += (int)blockDim.x) s_ring[WBASE + i] = ((const uint4*)p.w_packed)[i];
+  }
   __syncthreads();  // the only workgroup barrier of the kernel
 #ifdef RSA_RING_DEBUG
   const unsigned dbg = __builtin_amdgcn_readfirstlane(g_ring_dbg);
@@ -314,7 +329,7 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
 
   // weights: per (chunk, K step 0..8, cout tile, hi|lo) one 1 KiB A fragment, streamed from L2 WD K steps ahead
   constexpr int KSU = HM ? 5 : 9;  // K steps per unit
-  constexpr int WD = PROD == 3 ? 1 : (XRES ? RSA_RING_WDX : RSA_RING_WD1);  // K steps of weight prefetch (a one-product K step is 16 MFMAs = 256 cycles: less than an L2 hit under load)
+  constexpr int WD = (PROD == 3 || WL) ? 1 : (XRES ? RSA_RING_WDX : RSA_RING_WD1);  // K steps of weight prefetch (a one-product K step is 16 MFMAs = 256 cycles: less than an L2 hit under load)
   const int nks = nq * KSU;
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_packed, 0, (uint32_t)((int64_t)nks * ct_total * NHL * 64 * 16), 0x00020000);
   uint32_t woff[CTW];
@@ -331,6 +346,10 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
 #pragma unroll
       for (int hl = 0; hl < NHL; ++hl) {
         if (RING_DBG(4)) continue;
+        if (WL) {  // resident blob: fragment (K step s, cout tile c) = 64 units
+          wq[WD][c][hl] = *(const bf16x8*)&s_ring[WBASE + (s * ct_total + wct * CTW + c) * 64 + lane];
+          continue;
+        }
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, woff[c], (uint32_t)s * wstep + (uint32_t)hl * 1024u, 0);
         wq[WD][c][hl] = __builtin_bit_cast(bf16x8, v);
       }
@@ -361,13 +380,14 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
 #ifndef RSA_RING_STAGGER
 #define RSA_RING_STAGGER 0
 #endif
+#ifndef RSA_RING_STAGGER_SLEEP
+#define RSA_RING_STAGGER_SLEEP 100
+#endif
   if (RSA_RING_STAGGER) {
-    if (STREAMS == 2) {
-      if (g == 1)
-        for (int d = 0; d < nq * RSA_RING_STAGGER; ++d) __builtin_amdgcn_s_sleep(100);  // ~6400 cycles each
-    } else if (wave < 4) {
-      __builtin_amdgcn_s_setprio(1);
-    }
+    // the second half of the workgroup (waves 4-7: the SIMD partners of waves 0-3) starts late, so that one partner's epilogue (vector
+    // instructions, stores) falls into the other's multiply instead of both reaching the end of a tile together
+    if (STREAMS == 2 ? g == 1 : wave >= 4)
+      for (int d = 0; d < nq * RSA_RING_STAGGER; ++d) __builtin_amdgcn_s_sleep(RSA_RING_STAGGER_SLEEP);  // 64 cycles per unit
   }
 
   // blob K step of the step `koff` steps into unit c of the processing order (koff < 2 * KSU; past the last unit: the next tile's first ones)
@@ -497,6 +517,8 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
       ring_tile_coords(p.tile_order ? num_tiles - 1 - (tile0 + j * NWG) : tile0 + j * NWG, tiles_x, tiles_y, n, ty, tx);
       if (XRES == 2) {
         if (!RING_DBG(8)) epilogue_impl<NCT, CTW, NPT, 0, AC_LINEAR, 1, RSA_PF_F16>(p, acc, n, ty * TH, tx * TW, 0, wct, wpx, li, lg);
+      } else if (XRES == 3) {
+        if (!RING_DBG(8)) epilogue_impl<NCT, CTW, NPT, 0, XAC, 4, RSA_PF_F16>(p, acc, n, ty * TH, tx * TW, 0, wct, wpx, li, lg);
       } else if (XR) {
         if (!RING_DBG(8)) {
           if (p.res2_hi != nullptr)
@@ -521,7 +543,7 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
   }
 }
 
-template <int SHAPE, int UP, int OUTK, int HM = 0, int FMT = 0, int PROD = 3, int XRES = 0>
+template <int SHAPE, int UP, int OUTK, int HM = 0, int FMT = 0, int PROD = 3, int XRES = 0, int XAC = 0>
 static int launch_ring(const rsa_conv_params& p, hipStream_t stream) {
   constexpr int STREAMS = SHAPE == 2 ? 2 : 1;
   using R = RingGeoP<PROD>;
@@ -537,7 +559,7 @@ static int launch_ring(const rsa_conv_params& p, hipStream_t stream) {
   }();
   int gx = cus;  // one persistent workgroup per CU (the ring takes the whole LDS)
   if (gx > num_tiles) gx = (int)num_tiles;
-  hipLaunchKernelGGL((conv_ring<SHAPE, UP, OUTK, HM, FMT, PROD, XRES>), dim3((unsigned)gx, 1, 1), dim3((8 + STREAMS) * 64), 0, stream, p, ring_aux());
+  hipLaunchKernelGGL((conv_ring<SHAPE, UP, OUTK, HM, FMT, PROD, XRES, XAC>), dim3((unsigned)gx, 1, 1), dim3((8 + STREAMS) * 64), 0, stream, p, ring_aux());
   return (int)hipGetLastError();
 }
 

@@ -88,8 +88,10 @@ __device__ __forceinline__ void round4(const float (&v)[4], bf16x4& h, bf16x4& l
     f16x4_t hh, ll;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      hh[e] = (_Float16)v[e];
-      ll[e] = (_Float16)(v[e] - (float)hh[e]);
+      float ve = v[e];
+      asm("" : "+v"(ve));  // opaque: keeps the conversion of the residual from being fused with the arithmetic that made v (conv_common.h, split2)
+      hh[e] = (_Float16)ve;
+      ll[e] = (_Float16)(ve - (float)hh[e]);
     }
     h = __builtin_bit_cast(bf16x4, hh);
     lo4 = __builtin_bit_cast(bf16x4, ll);

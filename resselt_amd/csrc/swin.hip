@@ -129,9 +129,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const rsa_layernorm_para
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           if (p.out_fmt == RSA_PF_F16) {
-            const _Float16 hb = (_Float16)y[j];
+            float yj = y[j];
+            asm("" : "+v"(yj));  // opaque: see conv_common.h, split2
+            const _Float16 hb = (_Float16)yj;
             h[j] = __builtin_bit_cast(uint16_t, hb);
-            l[j] = __builtin_bit_cast(uint16_t, (_Float16)(y[j] - (float)hb));
+            l[j] = __builtin_bit_cast(uint16_t, (_Float16)(yj - (float)hb));
           } else {
             const __bf16 hb = (__bf16)y[j];
             h[j] = __builtin_bit_cast(uint16_t, hb);

@@ -294,3 +294,44 @@ def test_conv5_residual_from_the_ring(device, two, n, h, w):
         outs.append(tensors.planes_to_nchw(out, 64).cpu())
     assert torch.equal(outs[0], outs[1])
     assert (outs[0] - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize('act', ['mish', 'silu', 'gate_hi', 'gate_hilo', 'none', 'lrelu'])
+@pytest.mark.parametrize('out_lo', [False, True])
+def test_span_family_layer_direct_epilogue(device, act, out_lo):
+    """The re-parameterised 48 -> 48 layers of the SPAN family (reference archs/spanplus/arch.py:94-130) on the ring form with the weight
+    blob resident in LDS and one epilogue instantiation per activation class (conv_ring.h XRES 3): Mish, SiLU, the SPAB gate
+    `(out3 + x) * (sigmoid(out3) - 0.5)` with its shortcut from hi-only and from hi + lo planes, no activation, LeakyReLU."""
+    n, c, h, w = 2, 48, 37, 70
+    x = _rand((n, c, h, w), 51)
+    sc = _rand((n, c, h, w), 52)
+    wt = _rand((c, c, 3, 3), 53, 1.0 / (c * 9) ** 0.5)
+    b = _rand((c,), 54, 0.1)
+    y = _conv(_h(x), _h(wt), b)
+    wts = ops.ConvWeights.from_oihw(wt, b, 1, device=device, fmt=PF_F16)
+    xin = tensors.nchw_to_planes(x.to(device), with_lo=False, fmt=PF_F16)
+    out = tensors.Planes.empty(n, c // 8, h, w, device, with_lo=out_lo, fmt=PF_F16)
+    kw = {}
+    if act == 'mish':
+        ref, kw = F.mish(y), dict(act=L.ACT_MISH)
+    elif act == 'silu':
+        ref, kw = F.silu(y), dict(act=L.ACT_SILU)
+    elif act == 'lrelu':
+        ref, kw = F.leaky_relu(y, 0.1), dict(act=L.ACT_LRELU, act_param=0.1)
+    elif act == 'none':
+        ref = y
+    else:
+        res = tensors.nchw_to_planes(sc.to(device), with_lo=act == 'gate_hilo', fmt=PF_F16)
+        scv = tensors.planes_to_nchw(res, c).cpu()  # the shortcut as the planes hold it (11 or 22 bits)
+        ref, kw = (y + scv) * (torch.sigmoid(y) - 0.5), dict(act=L.ACT_SPAB_GATE, res1=(res, 0))
+    p = ops.conv_params(wts, xin, h, w, out=out, **kw)
+    assert 'XRES 3' in L.conv_kernel_name(p), L.conv_kernel_name(p)
+    ops.run_convs([p], device)
+    torch.cuda.synchronize()
+    assert L.ring_aborts() == 0
+    L.check_status('test')
+    got = tensors.planes_to_nchw(out, c).cpu()
+    scale = max(1.0, ref.abs().max().item())
+    # hi only: the value rounded to fp16; hi + lo: 22 bits; the activation functions run on hardware exp / rcp (1 ulp each)
+    tol = (2.0**-11 * 1.01 if not out_lo else 2e-6) * scale + 3e-6 * scale
+    assert (got - ref).abs().max().item() <= tol, (got - ref).abs().max().item()

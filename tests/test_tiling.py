@@ -141,6 +141,85 @@ def test_tile_parallel_u8_images_async_and_in_place(world):
     assert results[0]['strips'][1]['bytes_per_round'] == 96 * 80 * 3
 
 
+def _bench_like_cases(model, u8_model):
+    """The tile-parallel calls `bench.py --gpus 8` makes, at toy size (same structure: grids, halo clamping, sub-tiling, dtypes):
+      c2      8 x 1 full-width row bands of one image, fp32 tensors (padded receive buffer) and 8-bit images (bands gathered in place);
+      c5      ONE image, 2 x 4 tiles dealt round-robin, every tile run as sub-tiles by an inner single-device tiler (fp32 and 8-bit);
+      uneven  3 x 3 = 9 tiles on 8 ranks (a last round with one tile), idle: 2 x 2 = 4 tiles on 8 ranks (four ranks only join the collective)."""
+    from resselt_amd.tiling import upscale_tiled as ut
+
+    g = torch.Generator().manual_seed(21)
+    x_c2 = synth.synth_input((1, 3, 8 * 10, 18), seed=21)
+    img_c2 = torch.randint(0, 256, (1, 8 * 10, 18, 3), generator=g, dtype=torch.uint8)
+    x_c5 = synth.synth_input((1, 3, 32, 64), seed=22)
+    img_c5 = torch.randint(0, 256, (1, 32, 64, 3), generator=g, dtype=torch.uint8)
+    inner = lambda crop: ut(model, crop, 2, tile=(8 + 16, 16 + 16), halo=8)  # noqa: E731
+    inner_u8 = lambda crop: ut(u8_model, crop, 2, tile=(8 + 16, 16 + 16), halo=8)  # noqa: E731
+    return {
+        'c2_f32': (model, x_c2, dict(grid=(8, 1), halo=8)),
+        'c2_u8': (u8_model, img_c2, dict(grid=(8, 1), halo=8)),
+        'c5_f32': (inner, x_c5, dict(grid=(2, 4), halo=8)),
+        'c5_u8': (inner_u8, img_c5, dict(grid=(2, 4), halo=8)),
+        'uneven': (model, x_c5, dict(grid=(3, 3), halo=8)),
+        'idle': (u8_model, img_c5, dict(grid=(2, 2), halo=8)),
+    }
+
+
+def _bench_like_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        out = {}
+        for name, (fn, x, kw) in _bench_like_cases(_model(), _u8_model()).items():
+            tp = TileParallel(fn, scale=2, **kw)
+            y = tp(x)
+            out[name] = (y.numpy(), dict(tp.last_stats))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tile_parallel_eight_ranks_as_bench_runs_them():
+    """World size 8 over gloo on the CPU: exactly what `bench.py --config c2 --gpus 8` and `--config c5 --gpus 8` execute (no 8-GPU node has
+    run them yet), plus an uneven last round and idle ranks; every rank must end with the single-process result, bit for bit."""
+    world = 8
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_like_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    expect_stats = {
+        'c2_f32': dict(rounds=1, in_place=False, tile_dtype='torch.float32'),
+        'c2_u8': dict(rounds=1, in_place=True, tile_dtype='torch.uint8'),
+        'c5_f32': dict(rounds=1, in_place=False, tile_dtype='torch.float32'),
+        'c5_u8': dict(rounds=1, in_place=False, tile_dtype='torch.uint8'),
+        'uneven': dict(rounds=2, in_place=False, tile_dtype='torch.float32'),
+        'idle': dict(rounds=1, in_place=False, tile_dtype='torch.uint8'),
+    }
+    for name, (fn, x, kw) in _bench_like_cases(_model(), _u8_model()).items():
+        single = TileParallel(fn, scale=2, **kw)(x)  # no process group: the world-size-1 path over the same tile plan
+        for rank in range(world):
+            y, stats = results[rank][name]
+            assert torch.equal(torch.from_numpy(y), single), (name, rank)
+            for k, v in expect_stats[name].items():
+                assert stats[k] == v, (name, rank, k, stats)
+            assert stats['overlap'] is True
+    # the bytes that cross the links per round: an 8-bit band is a quarter of the same band in fp32
+    assert results[0]['c2_f32'][1]['bytes_per_round'] == 4 * results[0]['c2_u8'][1]['bytes_per_round']
+
+
 def _worker(rank, world, port, q):
     import torch.distributed as dist
 
