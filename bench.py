@@ -136,11 +136,28 @@ def cpu_baseline(sd, crop: int) -> dict:
     }
 
 
-def measured_traffic() -> dict:
+def _kernel_key(name: str):
+    """(shape, plane format, products) of a ring-kernel name in either spelling (bench.py's classes / tools/hbm_traffic.py's families)."""
+    import re
+
+    if 'conv_ring_pair' in name:
+        return ('pair',)
+    if 'conv_ring_up2' in name:
+        return ('up2',)
+    m = re.search(r'conv_ring<(\d)', name)
+    if not m:
+        return (name.split('(')[0].strip(),)
+    head = name.split('>')[0]
+    fmt = 'f16' if re.search(r'(?<!b)f16', head) else 'bf16'
+    pm = re.search(r'(?:f16|bf16),(\d)', head)
+    return (m.group(1), fmt, pm.group(1) if pm else '3')
+
+
+def measured_traffic(kernel: str = '') -> dict:
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (tools/hbm_traffic.py: separate FETCH_SIZE /
     WRITE_SIZE passes of this same command, gfx950 x2 FETCH correction).  Counters cannot be read from inside the timed process, so the
     summary carries the source hash of the library it was collected on; when that differs from the library loaded now the number is
-    stale and ``traffic`` is reported as null."""
+    stale and ``traffic`` is reported as null.  ``kernel``: the class bench.py found dominant; its family is looked up in the summary."""
     import glob
 
     from resselt_amd import build as B
@@ -157,6 +174,10 @@ def measured_traffic() -> dict:
     if rec.get('srchash') is None or rec.get('srchash') != have:
         return {'bytes': None, 'note': f'{name} was collected on another build (srchash {str(rec.get("srchash"))[:12]} != loaded {str(have)[:12]}): stale, not reported'}
     dom = rec.get('dominant', {})
+    for k in rec.get('kernels', []):
+        if kernel and _kernel_key(k.get('kernel', '')) == _kernel_key(kernel):
+            dom = k
+            break
     return {'bytes': dom.get('traffic_bytes_per_launch'), 'note': f'{name}: {dom.get("kernel")}, FETCH_SIZE x2 + WRITE_SIZE per launch; whole forward '
             f'{rec.get("traffic_GB_per_forward", 0):.1f} GB = {rec.get("traffic_over_algorithmic", 0):.2f}x the 258.5 GB layer-wise bf16 model'}  # fmt: skip
 
@@ -614,7 +635,7 @@ def main():
         priced = [c for c in classes if c['launches']]
         dom = max(priced, key=lambda c: c['ms_per_forward'])
         issued_tf = sum(c['tflops'] * c.get('products', 1) * c['ms_per_forward'] for c in priced) / max(1e-9, sum(c['ms_per_forward'] for c in priced))
-        traffic = measured_traffic() if (prec == 'mixed' and (H, W, args.blocks) == (1080, 1920, 23)) else {'bytes': None, 'note': 'PMC traffic is only collected for the default workload'}
+        traffic = measured_traffic(dom['kernel']) if (prec == 'mixed' and (H, W, args.blocks) == (1080, 1920, 23)) else {'bytes': None, 'note': 'PMC traffic is only collected for the default workload'}
         # which roof the dominant kernel is nearer to: its algorithmic FLOP rate over the dense MFMA peak, or its algorithmic bytes (every
         # operand once, in the layouts it reads and writes) per second over the HBM peak
         dom_mfma, dom_hbm = dom['tflops'] / MFMA_PEAK_TFLOPS, dom.get('gbs', 0.0) / HBM_PEAK_GBS
