@@ -383,6 +383,10 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
 #ifndef RSA_RING_STAGGER_SLEEP
 #define RSA_RING_STAGGER_SLEEP 100
 #endif
+#ifndef RSA_RING_PRIO_HI
+#define RSA_RING_PRIO_HI 0  // s_setprio of waves 4-7 (the younger half of the workgroup: the arbitration loser on every SIMD at equal priority)
+#endif
+  if (RSA_RING_PRIO_HI && wave >= 4) __builtin_amdgcn_s_setprio(RSA_RING_PRIO_HI);
   if (RSA_RING_STAGGER) {
     // the second half of the workgroup (waves 4-7: the SIMD partners of waves 0-3) starts late, so that one partner's epilogue (vector
     // instructions, stores) falls into the other's multiply instead of both reaching the end of a tile together
