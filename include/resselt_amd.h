@@ -483,6 +483,8 @@ typedef struct rsa_channel_attn_params {
   const float* temperature;  /* [heads] */
   float* workspace;          /* >= rsa_channel_attn_workspace_bytes() */
   void* w_packed;            /* [batch] blobs of rsa_packed_weight_bytes(32*heads, 4*heads, 1, products); off-diagonal blocks must be zero */
+  int32_t fmt;               /* enum rsa_plane_fmt of q / k AND of the packed weights written (0 = bf16, the default of a zeroed descriptor; round 4: fp16 planes) */
+  int32_t reserved1;         /* must be 0 */
 } rsa_channel_attn_params;
 int64_t rsa_channel_attn_workspace_bytes(int32_t batch, int32_t H, int32_t W, int32_t heads);
 int rsa_channel_attention_weights(const rsa_channel_attn_params* p, void* stream);
@@ -512,6 +514,8 @@ typedef struct rsa_dwconv_params {
   void* out_lo;              /* may be NULL */
   int64_t out_plane_stride;
   int64_t out_batch_stride;
+  int32_t fmt;               /* enum rsa_plane_fmt of every plane operand of this call (0 = bf16, the default of a zeroed descriptor; round 4: fp16 planes) */
+  int32_t reserved1;         /* must be 0 */
 } rsa_dwconv_params;
 int rsa_dwconv3x3(const rsa_dwconv_params* p, void* stream);
 /* Depthwise 5x5, zero padding 2, weight [planes*8][25]: OmniShift of RTMoSR re-parameterised to one kernel (archs/rtmosr/arch.py:253-289).
@@ -521,6 +525,9 @@ int rsa_dwconv5x5(const rsa_dwconv_params* p, void* stream);
 /* Per-pixel LayerNorm statistics over channels [0, C) of a plane range: stats[b][pixel] = (mean, 1/sqrt(var + eps)). */
 int rsa_plane_stats(const void* in_hi, const void* in_lo, int64_t plane_stride, int64_t batch_stride, int32_t batch, int32_t H, int32_t W,
                     int32_t C, float eps, float* stats, void* stream);
+/* the same over planes of format `fmt` (enum rsa_plane_fmt; rsa_plane_stats = bf16 planes) */
+int rsa_plane_stats_fmt(const void* in_hi, const void* in_lo, int64_t plane_stride, int64_t batch_stride, int32_t batch, int32_t H, int32_t W,
+                        int32_t C, float eps, int32_t fmt, float* stats, void* stream);
 
 /* channel_interaction of the AIM (arch.py:326-332): gate[b][c] = sigmoid( W2 . gelu(W1 . mean_pixels(x[b]) + b1) + b2 ).
  * BatchNorm(eval) folded into W1/b1 by the host.  Deterministic two-stage mean; `workspace` >= rsa_channel_gate_workspace_bytes(). */
@@ -541,6 +548,7 @@ typedef struct rsa_channel_gate_params {
   float* gate;               /* [batch][C] */
   int32_t relu;              /* 0 = GELU hidden, sigmoid gate (DAT); 1 = ReLU, sigmoid (the RCAN-style channel attention of HAT's CAB,
                                 archs/hat/arch.py:28-35); 2 = ReLU, Hardsigmoid (RTMoSR's CSELayer, archs/rtmosr/arch.py:7-22) */
+  int32_t fmt;               /* enum rsa_plane_fmt of every plane operand of this call (0 = bf16, the default of a zeroed descriptor; round 4: fp16 planes) */
 } rsa_channel_gate_params;
 int64_t rsa_channel_gate_workspace_bytes(int32_t batch, int32_t H, int32_t W, int32_t planes);
 int rsa_channel_gate(const rsa_channel_gate_params* p, void* stream);
@@ -571,6 +579,8 @@ typedef struct rsa_aim_params {
   void* out_lo;
   int64_t out_plane_stride;
   int64_t out_batch_stride;
+  int32_t fmt;               /* enum rsa_plane_fmt of every plane operand of this call (0 = bf16, the default of a zeroed descriptor; round 4: fp16 planes) */
+  int32_t reserved1;         /* must be 0 */
 } rsa_aim_params;
 int rsa_aim_combine(const rsa_aim_params* p, void* stream);
 

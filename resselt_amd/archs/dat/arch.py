@@ -217,10 +217,11 @@ def dat_param_shapes(in_chans, embed_dim, split_size, depth, num_heads, expansio
 
 class DAT(EngineModule):
     hyperparameters = {}
-    # 'mixed' (what 'auto' selects): the two Linear layers fed by a LayerNorm -- qkv and the SGFN's fc1, 70 % of the Linear
-    # multiply-accumulates -- run ONE fp16 product on the LayerNorm's fp16 hi planes.  Everything behind them reads bf16 split planes (the
-    # rectangular-window and channel attention, the depthwise convolutions, the AIM, the spatial gate), so their outputs, proj, fc2 and the
-    # 3x3 convolutions stay in the three-product format.
+    # 'mixed' (what 'auto' selects).  Round 4: the WHOLE transformer body runs on fp16 hi planes in one product -- qkv, proj, fc1, fc2, the
+    # rectangular-window attention (`rect_attention_kernel<1, T, f16>`), the channel attention's Gram matrix and its `attn @ v` (the weight
+    # blob is written in fp16), the depthwise convolutions, the AIM, the spatial gate (their descriptors carry the plane format) -- as HAT and
+    # DRCT have done since round 3.  The residual stream stays an f32 map; the 3x3 convolutions of the residual groups, conv_first,
+    # conv_after_body and the reconstruction head keep three bf16 products.  (Round 3: only qkv and fc1, the layers a LayerNorm feeds.)
     auto_precision = 'mixed'
     precisions = ('bf16x3', 'bf16', 'mixed')
     precision_table = {'mixed': (3, PF_BF16)}
@@ -228,7 +229,7 @@ class DAT(EngineModule):
     @staticmethod
     def layer_policy(name: str) -> tuple[int, int]:
         """(products, plane format of inputs and weights) of layer ``name`` under 'mixed'."""
-        return (1, PF_F16) if name.endswith(('.attn.qkv', '.ffn.fc1')) else (3, PF_BF16)
+        return (1, PF_F16) if name.endswith(('.attn.qkv', '.attn.proj', '.ffn.fc1', '.ffn.fc2')) else (3, PF_BF16)
 
     def __init__(self, *, img_size=64, in_chans=3, embed_dim=180, split_size=(8, 32), depth=(6, 6, 6, 6, 6, 6), num_heads=(6, 6, 6, 6, 6, 6),
                  expansion_factor=2.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1, use_chk=False,
@@ -423,14 +424,17 @@ class DAT(EngineModule):
         first = plan.f32map(n, C_, H, Wd)
         pool = [plan.f32map(n, C_, H, Wd) for _ in range(4)]
         mixed = products.name == 'mixed'
-        a_pl = plan.planes(n, cp, H, Wd, **(dict(with_lo=False, fmt=PF_F16) if mixed else dict(with_lo=with_lo)))  # norm1 / norm2 -> qkv / fc1
+        body_kw = dict(with_lo=False, fmt=PF_F16) if mixed else dict(with_lo=with_lo)  # the transformer body: fp16 hi planes under 'mixed'
+        bprod = 1 if mixed else int(products)  # matrix products of the body's attention kernels
+        bfmt = PF_F16 if mixed else products.fmt
+        a_pl = plan.planes(n, cp, H, Wd, **body_kw)  # norm1 / norm2 -> qkv / fc1
         n_pl = plan.planes(n, cp, H, Wd, with_lo) if mixed else a_pl  # the last LayerNorm -> conv_after_body (three products)
-        qkv_pl = plan.planes(n, 3 * hp_max, H, Wd, with_lo)
-        att_pl = plan.planes(n, hp_max, H, Wd, with_lo)
-        conv_pl = plan.planes(n, hp_max, H, Wd, with_lo)
-        comb_pl = plan.planes(n, hp_max, H, Wd, with_lo)
-        hid_pl = plan.planes(n, 2 * P1, H, Wd, with_lo)
-        gate_pl = plan.planes(n, P1, H, Wd, with_lo)
+        qkv_pl = plan.planes(n, 3 * hp_max, H, Wd, **body_kw)
+        att_pl = plan.planes(n, hp_max, H, Wd, **body_kw)
+        conv_pl = plan.planes(n, hp_max, H, Wd, **body_kw)
+        comb_pl = plan.planes(n, hp_max, H, Wd, **body_kw)
+        hid_pl = plan.planes(n, 2 * P1, H, Wd, **body_kw)
+        gate_pl = plan.planes(n, P1, H, Wd, **body_kw)
         body_pl = plan.planes(n, cp, H, Wd, with_lo)
         q4_a = plan.planes(n, (C_ // 4 + 7) // 8, H, Wd, with_lo) if self.resi == '3conv' else None
         q4_b = plan.planes(n, (C_ // 4 + 7) // 8, H, Wd, with_lo) if self.resi == '3conv' else None
@@ -444,7 +448,7 @@ class DAT(EngineModule):
         wdyn = {}
         if has_dctb:
             for heads in sorted({h for h, d in zip(self.num_heads, self.depth) if d >= 2}):
-                blob = int(lib.rsa_packed_weight_bytes(heads * HEAD_PAD, heads * 4, 1, int(products))) // 2
+                blob = int(lib.rsa_packed_weight_bytes(heads * HEAD_PAD, heads * 4, 1, bprod)) // 2
                 wdyn[heads] = torch.zeros((n, blob), dtype=torch.bfloat16, device=dev)  # off-diagonal blocks stay zero forever
                 plan.keep.append(wdyn[heads])
 
@@ -466,7 +470,8 @@ class DAT(EngineModule):
                 ap.batch, ap.H, ap.W, ap.Hp, ap.Wp = n, H, Wd, Hp, Wp
                 ap.win_h, ap.win_w = branch_geometry(self.split_size, idx)
                 ap.shift_h, ap.shift_w = branch_geometry(shift, idx) if shifted else (0, 0)
-                ap.heads, ap.head0, ap.heads_total, ap.products = heads // 2, idx * (heads // 2), heads, int(products)
+                ap.heads, ap.head0, ap.heads_total, ap.products = heads // 2, idx * (heads // 2), heads, bprod
+                ap.fmt = bfmt
                 ap.qkv_hi, ap.qkv_lo = qkv_pl.hi_ptr(), qkv_pl.lo_ptr()
                 ap.qkv_plane_stride, ap.qkv_batch_stride = qkv_pl.plane_stride, qkv_pl.batch_stride
                 ap.bias_frag = W[f'{b}.attn.bias{idx}'].data_ptr()
@@ -477,7 +482,8 @@ class DAT(EngineModule):
         def channel_attention(b, heads):
             hp = heads * 4
             cpar = L.ChannelAttnParams()
-            cpar.batch, cpar.H, cpar.W, cpar.heads, cpar.head_dim, cpar.products = n, H, Wd, heads, C_ // heads, int(products)
+            cpar.batch, cpar.H, cpar.W, cpar.heads, cpar.head_dim, cpar.products = n, H, Wd, heads, C_ // heads, bprod
+            cpar.fmt = bfmt
             cpar.q_hi, cpar.q_lo = qkv_pl.hi_ptr(0), qkv_pl.lo_ptr(0)
             cpar.k_hi, cpar.k_lo = qkv_pl.hi_ptr(hp), qkv_pl.lo_ptr(hp)
             cpar.plane_stride, cpar.batch_stride = qkv_pl.plane_stride, qkv_pl.batch_stride
@@ -486,7 +492,7 @@ class DAT(EngineModule):
             launch('rsa_channel_attention_weights', cpar)
             plan.count_launches(1)  # two kernels
             for bi in range(n):  # attn @ v: the weights differ per image
-                wts = ops.ConvWeights(wdyn[heads][bi], zero_bias, heads * HEAD_PAD, heads * HEAD_PAD, hp, 1, int(products))
+                wts = ops.ConvWeights(wdyn[heads][bi], zero_bias, heads * HEAD_PAD, heads * HEAD_PAD, hp, 1, bprod, fmt=bfmt)
                 src = Planes(qkv_pl.hi[bi : bi + 1], None if qkv_pl.lo is None else qkv_pl.lo[bi : bi + 1])
                 dst = Planes(att_pl.hi[bi : bi + 1], None if att_pl.lo is None else att_pl.lo[bi : bi + 1])
                 plan.conv(ops.conv_params(wts, src, H, Wd, in_plane0=2 * hp, cin_planes=hp, out=dst))
@@ -494,6 +500,7 @@ class DAT(EngineModule):
         def dwconv(weights, src, src_plane0, planes, out, act=L.ACT_NONE, stats_t=None, gamma=None, beta=None, mul=None, mul_plane0=0):
             dp = L.DwConvParams()
             dp.batch, dp.H, dp.W, dp.planes, dp.act = n, H, Wd, planes, act
+            dp.fmt = src.fmt  # (source, multiplier and output planes of a call share their format)
             dp.in_hi, dp.in_lo = src.hi_ptr(src_plane0), src.lo_ptr(src_plane0)
             dp.in_plane_stride, dp.in_batch_stride = src.plane_stride, src.batch_stride
             dp.weight, dp.bias = weights[0].data_ptr(), weights[1].data_ptr()
@@ -510,6 +517,7 @@ class DAT(EngineModule):
             w1, b1, w2, b2 = W[f'{a}.ci']
             gp = L.ChannelGateParams()
             gp.batch, gp.H, gp.W, gp.planes, gp.hidden = n, H, Wd, heads * 4, w1.shape[0]
+            gp.fmt = src.fmt
             gp.in_hi, gp.in_lo = src.hi_ptr(), src.lo_ptr()
             gp.in_plane_stride, gp.in_batch_stride = src.plane_stride, src.batch_stride
             gp.w1, gp.b1, gp.w2, gp.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
@@ -521,6 +529,7 @@ class DAT(EngineModule):
             w1, b1, w2, b2 = W[f'{a}.si']
             ap = L.AimParams()
             ap.batch, ap.H, ap.W, ap.planes, ap.hidden, ap.mode = n, H, Wd, heads * 4, w1.shape[0], mode
+            ap.fmt = att_pl.fmt
             ap.att_hi, ap.att_lo = att_pl.hi_ptr(), att_pl.lo_ptr()
             ap.att_plane_stride, ap.att_batch_stride = att_pl.plane_stride, att_pl.batch_stride
             ap.conv_hi, ap.conv_lo = conv_pl.hi_ptr(), conv_pl.lo_ptr()
@@ -532,8 +541,8 @@ class DAT(EngineModule):
 
         def plane_stats(src, plane0, channels):
             def run():
-                L.check(lib.rsa_plane_stats(src.hi_ptr(plane0), src.lo_ptr(plane0), src.plane_stride, src.batch_stride, n, H, Wd, channels, 1e-5,
-                                            stats.data_ptr(), stream()), 'rsa_plane_stats')  # fmt: skip
+                L.check(lib.rsa_plane_stats_fmt(src.hi_ptr(plane0), src.lo_ptr(plane0), src.plane_stride, src.batch_stride, n, H, Wd, channels, 1e-5,
+                                                src.fmt, stats.data_ptr(), stream()), 'rsa_plane_stats')  # fmt: skip
 
             plan.call(run)
             plan.count_launches(1)

@@ -23,8 +23,23 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-__device__ __forceinline__ void unit_f32(const bf16x8* hi, const bf16x8* lo, int64_t u, float (&v)[8]) {
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+
+// one 16-byte unit (8 channels of a pixel) of planes in format fmt (enum rsa_plane_fmt, wave-uniform) -> f32: hi (+ lo where the buffer has it)
+__device__ __forceinline__ void unit_f32(const bf16x8* hi, const bf16x8* lo, int64_t u, float (&v)[8], int fmt = RSA_PF_BF16) {
   const bf16x8 h = hi[u];
+  if (fmt == RSA_PF_F16) {
+    const f16x8_t hf = __builtin_bit_cast(f16x8_t, h);
+    if (lo != nullptr) {
+      const f16x8_t lf = __builtin_bit_cast(f16x8_t, lo[u]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (float)hf[j] + (float)lf[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (float)hf[j];
+    }
+    return;
+  }
   if (lo != nullptr) {
     const bf16x8 l = lo[u];
 #pragma unroll
@@ -35,7 +50,21 @@ __device__ __forceinline__ void unit_f32(const bf16x8* hi, const bf16x8* lo, int
   }
 }
 
-__device__ __forceinline__ void store_unit(bf16x8* hi, bf16x8* lo, int64_t u, const float (&v)[8]) {
+__device__ __forceinline__ void store_unit(bf16x8* hi, bf16x8* lo, int64_t u, const float (&v)[8], int fmt = RSA_PF_BF16) {
+  if (fmt == RSA_PF_F16) {
+    f16x8_t h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float vj = v[j];
+      asm("" : "+v"(vj));  // opaque: see conv_common.h, split2
+      const _Float16 hb = (_Float16)vj;
+      h[j] = hb;
+      l[j] = (_Float16)(vj - (float)hb);
+    }
+    hi[u] = __builtin_bit_cast(bf16x8, h);
+    if (lo != nullptr) lo[u] = __builtin_bit_cast(bf16x8, l);
+    return;
+  }
   bf16x8 h, l;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -597,8 +626,8 @@ __global__ __launch_bounds__(64) void channel_gram_kernel(const rsa_channel_attn
     for (int pl = 0; pl < 4; ++pl) {
       float qv[8], kv[8];
       if (tok < HW) {
-        unit_f32(q_hi, q_lo, pl * p.plane_stride + tok, qv);
-        unit_f32(k_hi, k_lo, pl * p.plane_stride + tok, kv);
+        unit_f32(q_hi, q_lo, pl * p.plane_stride + tok, qv, p.fmt);
+        unit_f32(k_hi, k_lo, pl * p.plane_stride + tok, kv, p.fmt);
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) qv[j] = kv[j] = 0.f;
@@ -664,9 +693,15 @@ __global__ __launch_bounds__(1024) void channel_attn_finish_kernel(const rsa_cha
   const int ct = 2 * head + (i >> 4);
   const int ln = (j >> 3) * 16 + (i & 15);
   const int64_t base = (((int64_t)head * nct + ct) * nhl) * 64 * 8 + ln * 8 + (j & 7);
-  const __bf16 hb = (__bf16)a;
-  w[base] = hb;
-  if (nhl == 2) w[base + 64 * 8] = (__bf16)(a - (float)hb);
+  if (p.fmt == RSA_PF_F16) {  // the blob is an opaque 16-bit container: fp16 fragments for the one-product fp16 form
+    const _Float16 hf = (_Float16)a;
+    ((_Float16*)w)[base] = hf;
+    if (nhl == 2) ((_Float16*)w)[base + 64 * 8] = (_Float16)(a - (float)hf);
+  } else {
+    const __bf16 hb = (__bf16)a;
+    w[base] = hb;
+    if (nhl == 2) w[base + 64 * 8] = (__bf16)(a - (float)hb);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ depthwise 3x3
@@ -701,7 +736,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const rsa_dwconv_params p) 
       if (yy < 0 || yy >= p.H || xx < 0 || xx >= p.W) continue;
       const int64_t q = (int64_t)yy * p.W + xx;
       float v[8];
-      unit_f32(in_hi, in_lo, q, v);
+      unit_f32(in_hi, in_lo, q, v, p.fmt);
       if (NORM) {
         const float mean = p.stats[((int64_t)n * HW + q) * 2], rstd = p.stats[((int64_t)n * HW + q) * 2 + 1];
 #pragma unroll
@@ -719,18 +754,18 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const rsa_dwconv_params p) 
     const bf16x8* m_hi = (const bf16x8*)p.mul_hi + (int64_t)n * p.mul_batch_stride + (int64_t)pl * p.mul_plane_stride;
     const bf16x8* m_lo = p.mul_lo ? (const bf16x8*)p.mul_lo + (int64_t)n * p.mul_batch_stride + (int64_t)pl * p.mul_plane_stride : nullptr;
     float mv[8];
-    unit_f32(m_hi, m_lo, pix, mv);
+    unit_f32(m_hi, m_lo, pix, mv, p.fmt);
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] *= mv[j];
   }
   bf16x8* o_hi = (bf16x8*)p.out_hi + (int64_t)n * p.out_batch_stride + (int64_t)pl * p.out_plane_stride;
   bf16x8* o_lo = p.out_lo ? (bf16x8*)p.out_lo + (int64_t)n * p.out_batch_stride + (int64_t)pl * p.out_plane_stride : nullptr;
-  store_unit(o_hi, o_lo, pix, acc);
+  store_unit(o_hi, o_lo, pix, acc, p.fmt);
 }
 
 // ------------------------------------------------------------------------------------------------ per-pixel LN statistics
 __global__ __launch_bounds__(256) void plane_stats_kernel(const bf16x8* in_hi, const bf16x8* in_lo, int64_t plane_stride, int64_t batch_stride,
-                                                          int64_t HW, int C, float eps, float* stats) {
+                                                          int64_t HW, int C, float eps, float* stats, int fmt) {
   const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int n = blockIdx.y;
   if (pix >= HW) return;
@@ -740,7 +775,7 @@ __global__ __launch_bounds__(256) void plane_stats_kernel(const bf16x8* in_hi, c
   float sum = 0.f;
   for (int pl = 0; pl < planes; ++pl) {
     float v[8];
-    unit_f32(hi, lo, pl * plane_stride + pix, v);
+    unit_f32(hi, lo, pl * plane_stride + pix, v, fmt);
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       if (pl * 8 + j < C) sum += v[j];
@@ -749,7 +784,7 @@ __global__ __launch_bounds__(256) void plane_stats_kernel(const bf16x8* in_hi, c
   float var = 0.f;
   for (int pl = 0; pl < planes; ++pl) {
     float v[8];
-    unit_f32(hi, lo, pl * plane_stride + pix, v);
+    unit_f32(hi, lo, pl * plane_stride + pix, v, fmt);
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       if (pl * 8 + j < C) {
@@ -778,7 +813,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const rsa_channel_gate
     const int64_t pix = (int64_t)chunk * CG_PIX + it * 256 + threadIdx.x;
     if (pix < HW) {
       float v[8];
-      unit_f32(hi, lo, pix, v);
+      unit_f32(hi, lo, pix, v, p.fmt);
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] += v[j];
     }
@@ -848,7 +883,7 @@ __global__ __launch_bounds__(256) void aim_kernel(const rsa_aim_params p) {
   for (int k = 0; k < 16; ++k) h[k] = 0.f;
   for (int pl = 0; pl < p.planes; ++pl) {
     float v[8];
-    unit_f32(s_hi, s_lo, pl * s_ps + pix, v);
+    unit_f32(s_hi, s_lo, pl * s_ps + pix, v, p.fmt);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       if (k < p.hidden) {
@@ -868,14 +903,14 @@ __global__ __launch_bounds__(256) void aim_kernel(const rsa_aim_params p) {
   bf16x8* o_lo = p.out_lo ? (bf16x8*)p.out_lo + (int64_t)n * p.out_batch_stride : nullptr;
   for (int pl = 0; pl < p.planes; ++pl) {
     float a[8], c[8], o[8];
-    unit_f32(a_hi, a_lo, pl * p.att_plane_stride + pix, a);
-    unit_f32(c_hi, c_lo, pl * p.conv_plane_stride + pix, c);
+    unit_f32(a_hi, a_lo, pl * p.att_plane_stride + pix, a, p.fmt);
+    unit_f32(c_hi, c_lo, pl * p.conv_plane_stride + pix, c, p.fmt);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float g = gate[pl * 8 + j];
       o[j] = p.mode == 0 ? a[j] * g + sg * c[j] : a[j] * sg + c[j] * g;
     }
-    store_unit(o_hi, o_lo, pl * p.out_plane_stride + pix, o);
+    store_unit(o_hi, o_lo, pl * p.out_plane_stride + pix, o, p.fmt);
   }
 }
 
@@ -980,6 +1015,7 @@ extern "C" int64_t rsa_channel_attn_workspace_bytes(int32_t batch, int32_t H, in
 
 extern "C" int rsa_channel_attention_weights(const rsa_channel_attn_params* p, void* stream) {
   if (p == nullptr) return set_error(RSA_E_ARG, "channel_attention_weights: null params");
+  if (p->fmt != RSA_PF_BF16 && p->fmt != RSA_PF_F16) return set_error(RSA_E_ARG, "channel_attention_weights: fmt must be an rsa_plane_fmt");
   if (p->batch < 1 || p->H < 1 || p->W < 1 || p->heads < 1 || p->head_dim < 1 || p->head_dim > 32)
     return set_error(RSA_E_ARG, "channel_attention_weights: bad geometry (head_dim must be 1..32)");
   if (p->products != 1 && p->products != 3) return set_error(RSA_E_UNSUPPORTED, "channel_attention_weights: products must be 1 or 3");
@@ -997,6 +1033,7 @@ extern "C" int rsa_channel_attention_weights(const rsa_channel_attn_params* p, v
 
 extern "C" int rsa_dwconv3x3(const rsa_dwconv_params* p, void* stream) {
   if (p == nullptr) return set_error(RSA_E_ARG, "dwconv3x3: null params");
+  if (p->fmt != RSA_PF_BF16 && p->fmt != RSA_PF_F16) return set_error(RSA_E_ARG, "dwconv3x3: fmt must be an rsa_plane_fmt");
   if (p->batch < 1 || p->H < 1 || p->W < 1 || p->planes < 1 || p->planes > 65535 || p->batch > 65535) return set_error(RSA_E_ARG, "dwconv3x3: bad geometry");
   if (p->act != RSA_ACT_NONE && p->act != RSA_ACT_GELU) return set_error(RSA_E_UNSUPPORTED, "dwconv3x3: act must be none or gelu");
   if (!p->in_hi || !p->weight || !p->bias || !p->out_hi) return set_error(RSA_E_ARG, "dwconv3x3: null pointer");
@@ -1020,6 +1057,7 @@ extern "C" int rsa_dwconv3x3(const rsa_dwconv_params* p, void* stream) {
 
 extern "C" int rsa_dwconv5x5(const rsa_dwconv_params* p, void* stream) {
   if (p == nullptr) return set_error(RSA_E_ARG, "dwconv5x5: null params");
+  if (p->fmt != RSA_PF_BF16 && p->fmt != RSA_PF_F16) return set_error(RSA_E_ARG, "dwconv5x5: fmt must be an rsa_plane_fmt");
   if (p->batch < 1 || p->H < 1 || p->W < 1 || p->planes < 1 || p->planes > 65535 || p->batch > 65535) return set_error(RSA_E_ARG, "dwconv5x5: bad geometry");
   if (p->act != RSA_ACT_NONE || p->stats != nullptr) return set_error(RSA_E_UNSUPPORTED, "dwconv5x5: no activation / normalisation variant is compiled");
   if (!p->in_hi || !p->weight || !p->bias || !p->out_hi) return set_error(RSA_E_ARG, "dwconv5x5: null pointer");
@@ -1032,15 +1070,20 @@ extern "C" int rsa_dwconv5x5(const rsa_dwconv_params* p, void* stream) {
   return rc ? set_error(rc, "dwconv5x5: launch failed") : RSA_OK;
 }
 
-extern "C" int rsa_plane_stats(const void* in_hi, const void* in_lo, int64_t plane_stride, int64_t batch_stride, int32_t batch, int32_t H, int32_t W,
-                               int32_t C, float eps, float* stats, void* stream) {
+extern "C" int rsa_plane_stats_fmt(const void* in_hi, const void* in_lo, int64_t plane_stride, int64_t batch_stride, int32_t batch, int32_t H, int32_t W,
+                                   int32_t C, float eps, int32_t fmt, float* stats, void* stream) {
   if (!in_hi || !stats || batch < 1 || batch > 65535 || H < 1 || W < 1 || C < 1) return set_error(RSA_E_ARG, "plane_stats: bad argument");
+  if (fmt != RSA_PF_BF16 && fmt != RSA_PF_F16) return set_error(RSA_E_ARG, "plane_stats: fmt must be an rsa_plane_fmt");
   if (misaligned(in_hi) || misaligned(in_lo)) return set_error(RSA_E_ALIGN, "plane_stats: maps must be 16-byte aligned");
   const int64_t HW = (int64_t)H * W;
   hipLaunchKernelGGL(plane_stats_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)batch), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)in_hi,
-                     (const bf16x8*)in_lo, plane_stride, batch_stride, HW, C, eps, stats);
+                     (const bf16x8*)in_lo, plane_stride, batch_stride, HW, C, eps, stats, fmt);
   const hipError_t rc = hipGetLastError();
   return rc ? set_error(rc, "plane_stats: launch failed") : RSA_OK;
+}
+extern "C" int rsa_plane_stats(const void* in_hi, const void* in_lo, int64_t plane_stride, int64_t batch_stride, int32_t batch, int32_t H, int32_t W,
+                               int32_t C, float eps, float* stats, void* stream) {
+  return rsa_plane_stats_fmt(in_hi, in_lo, plane_stride, batch_stride, batch, H, W, C, eps, RSA_PF_BF16, stats, stream);
 }
 
 extern "C" int64_t rsa_channel_gate_workspace_bytes(int32_t batch, int32_t H, int32_t W, int32_t planes) {
@@ -1051,6 +1094,7 @@ extern "C" int64_t rsa_channel_gate_workspace_bytes(int32_t batch, int32_t H, in
 
 extern "C" int rsa_channel_gate(const rsa_channel_gate_params* p, void* stream) {
   if (p == nullptr) return set_error(RSA_E_ARG, "channel_gate: null params");
+  if (p->fmt != RSA_PF_BF16 && p->fmt != RSA_PF_F16) return set_error(RSA_E_ARG, "channel_gate: fmt must be an rsa_plane_fmt");
   if (p->batch < 1 || p->batch > 65535 || p->H < 1 || p->W < 1 || p->planes < 1 || p->planes > 64 || p->hidden < 1 || p->hidden > 128)
     return set_error(RSA_E_ARG, "channel_gate: bad geometry (planes <= 64, hidden <= 128)");
   if (!p->in_hi || !p->w1 || !p->b1 || !p->w2 || !p->b2 || !p->workspace || !p->gate) return set_error(RSA_E_ARG, "channel_gate: null pointer");
@@ -1066,6 +1110,7 @@ extern "C" int rsa_channel_gate(const rsa_channel_gate_params* p, void* stream) 
 
 extern "C" int rsa_aim_combine(const rsa_aim_params* p, void* stream) {
   if (p == nullptr) return set_error(RSA_E_ARG, "aim_combine: null params");
+  if (p->fmt != RSA_PF_BF16 && p->fmt != RSA_PF_F16) return set_error(RSA_E_ARG, "aim_combine: fmt must be an rsa_plane_fmt");
   if (p->batch < 1 || p->batch > 65535 || p->H < 1 || p->W < 1 || p->planes < 1 || p->hidden < 1 || p->hidden > 16 || (p->mode != 0 && p->mode != 1))
     return set_error(RSA_E_ARG, "aim_combine: bad geometry (hidden <= 16, mode 0 or 1)");
   if (!p->att_hi || !p->conv_hi || !p->gate || !p->w1 || !p->b1 || !p->w2 || !p->out_hi) return set_error(RSA_E_ARG, "aim_combine: null pointer");

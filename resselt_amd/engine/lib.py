@@ -289,6 +289,8 @@ class ChannelAttnParams(C.Structure):
         ('temperature', C.c_void_p),
         ('workspace', C.c_void_p),
         ('w_packed', C.c_void_p),
+        ('fmt', C.c_int32),
+        ('reserved1', C.c_int32),
     ]
 
 
@@ -318,6 +320,8 @@ class DwConvParams(C.Structure):
         ('out_lo', C.c_void_p),
         ('out_plane_stride', C.c_int64),
         ('out_batch_stride', C.c_int64),
+        ('fmt', C.c_int32),
+        ('reserved1', C.c_int32),
     ]
 
 
@@ -341,6 +345,7 @@ class ChannelGateParams(C.Structure):
         ('workspace', C.c_void_p),
         ('gate', C.c_void_p),
         ('relu', C.c_int32),
+        ('fmt', C.c_int32),
     ]
 
 
@@ -397,6 +402,8 @@ class AimParams(C.Structure):
         ('out_lo', C.c_void_p),
         ('out_plane_stride', C.c_int64),
         ('out_batch_stride', C.c_int64),
+        ('fmt', C.c_int32),
+        ('reserved1', C.c_int32),
     ]
 
 
@@ -433,6 +440,7 @@ EXPORTS = (
     'rsa_channel_attention_weights',
     'rsa_dwconv3x3',
     'rsa_plane_stats',
+    'rsa_plane_stats_fmt',
     'rsa_channel_gate_workspace_bytes',
     'rsa_channel_gate',
     'rsa_aim_combine',
@@ -556,6 +564,9 @@ def load() -> C.CDLL:
     lib.rsa_plane_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
                                     C.c_void_p]  # fmt: skip
     lib.rsa_plane_stats.restype = C.c_int
+    lib.rsa_plane_stats_fmt.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32,
+                                        C.c_void_p, C.c_void_p]  # fmt: skip
+    lib.rsa_plane_stats_fmt.restype = C.c_int
     lib.rsa_dwconv5x5.argtypes = [C.POINTER(DwConvParams), C.c_void_p]
     lib.rsa_dwconv5x5.restype = C.c_int
     lib.rsa_gated_shuffle_mul.argtypes = [C.POINTER(GatedShuffleParams), C.c_void_p]

@@ -266,3 +266,104 @@ def test_dat_vs_oracle_dtypes_and_precision(device):
     e1 = (m(x.to(device)).cpu() - ref).abs().max().item()
     print(f'DAT(2x4) plain bf16 max-abs {e1:.3e}')
     assert e1 <= 5e-2 * max(1.0, ref.abs().max().item())
+
+
+def _h16(x):
+    return x.half().float()
+
+
+def test_stream_kernels_on_fp16_planes(device):
+    """Round 4: the depthwise convolution (with the spatial gate's LayerNorm statistics and multiplier), the AIM, the channel gate and the
+    channel attention weights on fp16 hi-only planes (`fmt = RSA_PF_F16` in their descriptors): what DAT's 'mixed' policy runs.
+    Inputs are fp16 values, so the kernels see them exactly; outputs are rounded to fp16 (2^-11 relative)."""
+    from resselt_amd.engine.tensors import PF_F16
+
+    lib = L.load()
+    n, c, h, w = 2, 48, 19, 27
+    planes = c // 8
+    tol = lambda ref: (2.0**-11 * 1.01 + 3e-5) * max(1.0, ref.abs().max().item())  # noqa: E731
+    # ---- depthwise 3x3 over LayerNorm(x) * multiplier ----
+    x, m = _h16(_rand((n, c, h, w), 1, 2.0)), _h16(_rand((n, c, h, w), 6, 1.5))
+    wt, b = _rand((c, 1, 3, 3), 2, 0.4), _rand((c,), 3, 0.2)
+    g, beta = 1 + _rand((c,), 4, 0.3), _rand((c,), 5, 0.2)
+    ref = F.conv2d(F.layer_norm(x.permute(0, 2, 3, 1), (c,), g, beta, 1e-5).permute(0, 3, 1, 2), wt, b, padding=1, groups=c) * m
+    xp, mp = tensors.nchw_to_planes(x.to(device), False, PF_F16), tensors.nchw_to_planes(m.to(device), False, PF_F16)
+    out = tensors.Planes.empty(n, planes, h, w, device, False, PF_F16)
+    keep = [t.to(device).contiguous() for t in (wt.reshape(c, 9), b, g, beta)]
+    stats = torch.empty((n, h * w, 2), dtype=torch.float32, device=device)
+    L.check(lib.rsa_plane_stats_fmt(xp.hi_ptr(), None, xp.plane_stride, xp.batch_stride, n, h, w, c, 1e-5, PF_F16, stats.data_ptr(), _stream(device)), 'rsa_plane_stats_fmt')
+    dp = L.DwConvParams()
+    dp.batch, dp.H, dp.W, dp.planes, dp.act, dp.fmt = n, h, w, planes, L.ACT_NONE, PF_F16
+    dp.in_hi, dp.in_plane_stride, dp.in_batch_stride = xp.hi_ptr(), xp.plane_stride, xp.batch_stride
+    dp.weight, dp.bias, dp.stats, dp.gamma, dp.beta = keep[0].data_ptr(), keep[1].data_ptr(), stats.data_ptr(), keep[2].data_ptr(), keep[3].data_ptr()
+    dp.mul_hi, dp.mul_plane_stride, dp.mul_batch_stride = mp.hi_ptr(), mp.plane_stride, mp.batch_stride
+    dp.out_hi, dp.out_plane_stride, dp.out_batch_stride = out.hi_ptr(), out.plane_stride, out.batch_stride
+    L.check(lib.rsa_dwconv3x3(C.byref(dp), _stream(device)), 'rsa_dwconv3x3')
+    torch.cuda.synchronize()
+    assert (tensors.planes_to_nchw(out, c).cpu() - ref).abs().max().item() <= tol(ref)
+    # ---- AIM combine (mode 0) with the channel gate of the same maps ----
+    att, conv = _h16(_rand((n, c, h, w), 11, 2.0)), _h16(_rand((n, c, h, w), 12, 2.0))
+    hidden = 6
+    w1, b1, w2, b2 = _rand((hidden, c), 14, 0.2), _rand((hidden,), 15, 0.2), _rand((hidden,), 16, 0.5), 0.1
+    gw1, gb1, gw2, gb2 = _rand((8, c), 21, 0.2), _rand((8,), 22, 0.2), _rand((c, 8), 23, 0.4), _rand((c,), 24, 0.2)
+    gate_ref = torch.sigmoid(F.linear(F.gelu(F.linear(conv.mean(dim=(2, 3)), gw1, gb1)), gw2, gb2))
+    ap_, cp_ = tensors.nchw_to_planes(att.to(device), False, PF_F16), tensors.nchw_to_planes(conv.to(device), False, PF_F16)
+    ws = torch.empty((int(lib.rsa_channel_gate_workspace_bytes(n, h, w, planes)) // 4,), dtype=torch.float32, device=device)
+    gate = torch.empty((n, c), dtype=torch.float32, device=device)
+    gkeep = [t.to(device).contiguous() for t in (gw1, gb1, gw2, gb2)]
+    gp = L.ChannelGateParams()
+    gp.batch, gp.H, gp.W, gp.planes, gp.hidden, gp.fmt = n, h, w, planes, 8, PF_F16
+    gp.in_hi, gp.in_plane_stride, gp.in_batch_stride = cp_.hi_ptr(), cp_.plane_stride, cp_.batch_stride
+    gp.w1, gp.b1, gp.w2, gp.b2 = (t.data_ptr() for t in gkeep)
+    gp.workspace, gp.gate = ws.data_ptr(), gate.data_ptr()
+    L.check(lib.rsa_channel_gate(C.byref(gp), _stream(device)), 'rsa_channel_gate')
+    torch.cuda.synchronize()
+    assert (gate.cpu() - gate_ref).abs().max().item() <= 2e-6
+    s = F.conv2d(F.gelu(F.conv2d(att, w1[:, :, None, None], b1)), w2[None, :, None, None], torch.tensor([b2]))
+    ref = att * gate_ref[:, :, None, None] + torch.sigmoid(s) * conv
+    out2 = tensors.Planes.empty(n, planes, h, w, device, False, PF_F16)
+    akeep = [t.to(device).contiguous() for t in (w1, b1, w2)]
+    ap = L.AimParams()
+    ap.batch, ap.H, ap.W, ap.planes, ap.hidden, ap.mode, ap.fmt = n, h, w, planes, hidden, 0, PF_F16
+    ap.att_hi, ap.att_plane_stride, ap.att_batch_stride = ap_.hi_ptr(), ap_.plane_stride, ap_.batch_stride
+    ap.conv_hi, ap.conv_plane_stride, ap.conv_batch_stride = cp_.hi_ptr(), cp_.plane_stride, cp_.batch_stride
+    ap.gate, ap.w1, ap.b1, ap.w2, ap.b2 = gate.data_ptr(), akeep[0].data_ptr(), akeep[1].data_ptr(), akeep[2].data_ptr(), b2
+    ap.out_hi, ap.out_plane_stride, ap.out_batch_stride = out2.hi_ptr(), out2.plane_stride, out2.batch_stride
+    L.check(lib.rsa_aim_combine(C.byref(ap), _stream(device)), 'rsa_aim_combine')
+    torch.cuda.synchronize()
+    assert (tensors.planes_to_nchw(out2, c).cpu() - ref).abs().max().item() <= tol(ref)
+    # ---- channel attention: Gram matrix of fp16 q / k, fp16 weight blob, attn @ v as a one-product fp16 convolution ----
+    heads, hd = 3, 14
+    N = h * w
+    q, k, v = (_h16(_rand((n, heads, hd, N), sd, 1.5)) for sd in (31, 32, 33))
+    temp = 1 + _rand((heads,), 34, 0.5)
+    attn = ((F.normalize(q, dim=-1) @ F.normalize(k, dim=-1).transpose(-2, -1)) * temp.view(1, heads, 1, 1)).softmax(-1)
+    ref = _h16(attn) @ v  # the packed weights are fp16 values
+
+    def padded(t):
+        o = torch.zeros((n, heads, 32, N))
+        o[:, :, :hd] = t
+        return o.reshape(n, heads * 32, h, w)
+
+    qkv = tensors.nchw_to_planes(torch.cat([padded(q), padded(k), padded(v)], dim=1).to(device), False, PF_F16)
+    hp = heads * 4
+    ws2 = torch.empty((int(lib.rsa_channel_attn_workspace_bytes(n, h, w, heads)) // 4,), dtype=torch.float32, device=device)
+    blob = int(lib.rsa_packed_weight_bytes(heads * 32, hp, 1, 1)) // 2
+    wdyn = torch.zeros((n, blob), dtype=torch.bfloat16, device=device)
+    td = temp.to(device)
+    cpar = L.ChannelAttnParams()
+    cpar.batch, cpar.H, cpar.W, cpar.heads, cpar.head_dim, cpar.products, cpar.fmt = n, h, w, heads, hd, 1, PF_F16
+    cpar.q_hi, cpar.k_hi = qkv.hi_ptr(0), qkv.hi_ptr(hp)
+    cpar.plane_stride, cpar.batch_stride = qkv.plane_stride, qkv.batch_stride
+    cpar.temperature, cpar.workspace, cpar.w_packed = td.data_ptr(), ws2.data_ptr(), wdyn.data_ptr()
+    L.check(lib.rsa_channel_attention_weights(C.byref(cpar), _stream(device)), 'rsa_channel_attention_weights')
+    out3 = tensors.Planes.empty(n, hp, h, w, device, False, PF_F16)
+    bias = pad_bias(None, heads * 32, device)
+    for bi in range(n):
+        wts = ops.ConvWeights(wdyn[bi], bias, heads * 32, heads * 32, hp, 1, 1, fmt=PF_F16)
+        src = tensors.Planes(qkv.hi[bi : bi + 1], None)
+        dst = tensors.Planes(out3.hi[bi : bi + 1], None)
+        ops.run_convs([ops.conv_params(wts, src, h, w, in_plane0=2 * hp, cin_planes=hp, out=dst)], device)
+    torch.cuda.synchronize()
+    got = tensors.planes_to_nchw(out3, heads * 32).cpu().reshape(n, heads, 32, N)
+    assert (got[:, :, :hd] - ref).abs().max().item() <= tol(ref)
