@@ -12,7 +12,7 @@ import resselt_amd  # noqa: E402
 from resselt_amd.utils import synth  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else 'dat'
-prec = sys.argv[2] if len(sys.argv) > 2 else 'bf16x3'
+prec = sys.argv[2] if len(sys.argv) > 2 else 'auto'
 dev = torch.device('cuda:0')
 if which == 'dat':
     sd = synth.dat_state_dict(embed_dim=180, depth=(6,) * 6, num_heads=(6,) * 6, split_size=(8, 32), expansion_factor=4.0, upscale=4, img_size=64)
