@@ -23,6 +23,9 @@ elif which == 'swinir':
 elif which == 'hat':
     sd = synth.hat_state_dict(embed_dim=180, depths=(6,) * 6, num_heads=(6,) * 6, window=16, upscale=4, mlp_ratio=2.0)
     shape, dt = (1, 3, 512, 512), torch.bfloat16
+elif which == 'drct':
+    sd = synth.drct_state_dict(num_layers=6, upscale=4)
+    shape, dt = (1, 3, 512, 512), torch.bfloat16
 elif which == 'spanplus':
     sd = synth.spanplus_state_dict(upscale=4, upsampler='ps')
     shape, dt = (8, 3, 512, 512), torch.float16
