@@ -216,10 +216,13 @@ def kernel_classes(model, reps: int, x=None) -> list:
             if i + 1 < len(arr) and L.conv_pair_fusable(arr[i], arr[i + 1]):
                 q = arr[i + 1]
                 flop += 2.0 * 9 * cins[i + 1] * q.cout * q.H * q.W * q.batch
-                # every operand once: the common input planes ONCE, both outputs (layer B's last 32 input channels never leave the chip)
-                nbytes = p.cin_planes * 16 * p.batch * p.H * p.W + 2 * ((p.cout + 7) // 8) * 16 * p.batch * p.H * p.W
+                # ALGORITHMIC bytes of the launch = SURVEY.md 8d's layer-wise model of the TWO layers it computes (every operand of every layer once:
+                # conv1 + conv2 = 192 + 256 B, conv3 + conv4 = 320 + 384 B per pixel at 2 B per element) -- the figure the unfused launches were
+                # priced with.  What the fused launch has to move at least (common input once, both outputs) is `fused_bytes_per_launch`.
+                nbytes = conv_algorithmic_bytes(p) + conv_algorithmic_bytes(q)
+                fused = p.cin_planes * 16 * p.batch * p.H * p.W + 2 * ((p.cout + 7) // 8) * 16 * p.batch * p.H * p.W
                 two = (L.ConvParams * 2)(arr[i], arr[i + 1])
-                launches.append((lambda two=two: L.conv2d_list(two, stream), 'rsa::conv_ring_pair (two growth convolutions of a dense block in one launch, one fp16 product)', flop, nbytes, 1))
+                launches.append((lambda two=two: L.conv2d_list(two, stream), 'rsa::conv_ring_pair (two growth convolutions of a dense block in one launch, one fp16 product)', flop, nbytes, 1, fused))
                 i += 2
                 continue
             one = (L.ConvParams * 1)(p)
@@ -240,12 +243,13 @@ def kernel_classes(model, reps: int, x=None) -> list:
     timed = [(l, us) for l, us in zip(launches, total_us) if l[1] is not None]
     launches, total_us = [l for l, _ in timed], [us for _, us in timed]
     groups: dict = {}
-    for (one, name, flop, nbytes, prod), us in zip(launches, total_us):
-        g = groups.setdefault(name, {'kernel': name, 'launches': 0, 'us': 0.0, 'flop': 0.0, 'bytes': 0.0, 'products': prod})
+    for (one, name, flop, nbytes, prod, *extra), us in zip(launches, total_us):
+        g = groups.setdefault(name, {'kernel': name, 'launches': 0, 'us': 0.0, 'flop': 0.0, 'bytes': 0.0, 'products': prod, 'fused': 0.0})
         g['launches'] += 1
         g['us'] += us
         g['flop'] += flop
         g['bytes'] += nbytes
+        g['fused'] += extra[0] if extra else 0.0
     out = []
     for g in groups.values():
         out.append({
@@ -256,8 +260,9 @@ def kernel_classes(model, reps: int, x=None) -> list:
             'flop_per_launch': round(g['flop'] / g['launches']),
             'tflops': round(g['flop'] / g['us'] / 1e6, 2),
             'products': g['products'],
-            'bytes_per_launch': round(g['bytes'] / g['launches']),  # every operand once, in the layouts this launch reads and writes
+            'bytes_per_launch': round(g['bytes'] / g['launches']),  # every operand of every layer of the launch once, in the layouts it reads and writes
             'gbs': round(g['bytes'] / g['us'] / 1e3, 1),
+            **({'fused_bytes_per_launch': round(g['fused'] / g['launches'])} if g['fused'] else {}),
         })  # fmt: skip
     out.sort(key=lambda c: -c['ms_per_forward'])
     if other_us > 0.0:
@@ -680,6 +685,7 @@ def main():
                 'frac_mfma': round(dom_mfma, 4),
                 'frac_hbm': round(dom_hbm, 4),
                 'bytes_per_launch': dom.get('bytes_per_launch'),
+                'fused_bytes_per_launch': dom.get('fused_bytes_per_launch'),  # a fused launch: what it must move at least (common input once)
                 'traffic': traffic['bytes'],
                 'traffic_note': traffic['note'],
                 'avg_launch_us': dom['avg_us'],
