@@ -151,7 +151,22 @@ typedef struct rsa_conv_params {
   int32_t tile_order; /* ring schedule only: 0 = output tiles in band order from the top of the map, 1 = the same order reversed (bottom first).
                          Alternating it between consecutive layers makes a layer start on the rows its producer wrote last, which are still in
                          the 256 MB Infinity Cache (a 1080p layer moves 0.4-0.9 GB); other schedules ignore it.  Any other value: RSA_E_ARG */
+  /* Round 4: the lo halves of an fp16 residual stream as 8-bit codes.  A residual dense block's `x5 * 0.2 + x` (reference
+   * utilities/block.py:463-465) carries its stream as hi (fp16) + lo; |lo| is at most half an ulp of hi = 2^12 f32 ulps, so a signed byte
+   * codes it as the distance from f32(hi) to the value in steps of 32 f32 ulps, counted along the f32 bit patterns:
+   *   code = min((sat16(bits(v) - bits(f32(hi))) + 16) >> 5, 127) & 0xff,   value = as_float(bits(f32(hi)) + (code << 5)).
+   * hi + code keep 19 significant bits (fp16 hi + fp16 lo: 22) and the stream is 3 bytes per channel instead of 4; with hi = 0 or subnormal
+   * any code decodes to within 2^-24 of the value, a non-finite hi keeps the stream's hi non-finite.  An lo8 plane holds 8-byte units
+   * [n][plane][y][x][8 codes]: the plane stride is that of the hi planes (in units), the batch stride is lo8_batch_stride (8-byte units).
+   * Bits of lo8_flags: RSA_LO8_RES1 (res1_lo), RSA_LO8_RES2 (res2_lo), RSA_LO8_OUT (out_lo); only with fp16 planes (res_fmt / out_fmt =
+   * RSA_PF_F16) and plane residuals / outputs that have hi + lo. */
+  int32_t lo8_flags;
+  int32_t reserved_lo8;     /* must be 0 */
+  int64_t lo8_batch_stride; /* 8-byte units between images of an lo8 buffer (shared by the flagged operands) */
 } rsa_conv_params;
+#define RSA_LO8_RES1 1
+#define RSA_LO8_RES2 2
+#define RSA_LO8_OUT 4
 
 /* Launch `n` fused convolutions in order on `stream` (one host call per forward pass).  Both return RSA_E_INTERNAL, without launching,
  * when a kernel of an EARLIER call has reported a protocol failure that rsa_check_status has not yet been asked about. */

@@ -14,6 +14,7 @@ reference's old-arch names; the forward pass is the launch list below instead of
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -121,6 +122,7 @@ class RRDBNet(EngineModule):
         self.scale = scale // shuffle_factor if shuffle_factor else scale
         self.tail_band_rows = 272  # low-resolution rows per band of the 2x / 4x tail (bounds the plan's HR buffers; >= image height: one band)
         self.plane_residuals = True  # residual stream kept as split planes only (False: the f32-map plan; A/B and plain-bf16 mode)
+        self.stream_lo8 = os.environ.get('RSA_STREAM_LO8', '1') != '0'  # 'mixed': lo halves of the residual stream as 8-bit codes (A/B: RSA_STREAM_LO8=0)
         if plus or num_filters != 64:
             # the 'mixed' table is built for the x4plus / x2plus / ESRGAN trunk (64 channels: the fp16x3 trunk convolution is the four-tile
             # ring kernel); ESRGAN+ adds f32 side maps it has no plan for.  Such checkpoints run the conservative mode under 'auto'.
@@ -189,8 +191,15 @@ class RRDBNet(EngineModule):
         # 'mixed': the workspaces are fp16; the trunk channels x (planes 0..pf) keep hi + lo -- the residual stream, 22 bits -- and the growth
         # channels x1..x4 hi only (their one-product consumers never read lo): 2 bytes per channel read and written instead of 4.
         plane_res = mixed or (with_lo and self.plane_residuals)
+        # Round 4: the stream's lo halves travel as 8-bit codes (offsets from hi in 1/254 ulp: 3 bytes per channel instead of 4; rsa_conv_params.lo8_flags) from conv_first to
+        # the last dense block, whose output the trunk convolution reads as fp16 hi + lo operands.  Same accuracy (1.2e-4 against fp32:
+        # tests/test_precision_policy.py), 128-192 B per pixel less traffic in every conv5.
+        lo8 = mixed and self.stream_lo8
         if mixed:
             ws = [plan.planes(n, pf + 4 * pg, h, w, True, PF_F16, lo_planes=pf) for _ in range(3)]
+            if lo8:
+                for b_ in ws:
+                    b_.with_lo8(pf)
         else:
             ws = [plan.planes(n, pf + 4 * pg, h, w, with_lo) for _ in range(3 if plane_res else 2)]
         fea = plan.f32map(n, nf, h, w)
@@ -202,7 +211,7 @@ class RRDBNet(EngineModule):
             ops.nchw_to_planes(x, x_pl, unshuffle=sf or 1)
 
         # fea conv (arch.py:74-80): split planes into workspace 0 and the f32 copy the trunk shortcut adds at the end
-        plan.conv(ops.conv_params(W['model.0'], x_pl, h, w, out=ws[0], out_plane_off=0, out_f32=fea))
+        plan.conv(ops.conv_params(W['model.0'], x_pl, h, w, out=ws[0], out_plane_off=0, out_f32=fea, out_lo8=lo8))
         cur_f32, cur_ws = fea, 0
         free = list(pool)
         c11 = plan.f32map(n, gc, h, w) if self.plus else None
@@ -224,9 +233,11 @@ class RRDBNet(EngineModule):
                         kw.update(res1=x2_f32, alpha=1.0)
                     plan.conv(ops.conv_params(W[f'{p}.conv{j}.0'], a, h, w, **kw))
                 if plane_res:
-                    kw = dict(cin_planes=pf + 4 * pg, res1=(a, 0), alpha=0.2, out=b, out_plane_off=0)
+                    l8 = ('lo8',) if lo8 else ()
+                    kw = dict(cin_planes=pf + 4 * pg, res1=(a, 0, *l8), alpha=0.2, out=b, out_plane_off=0,
+                              out_lo8=lo8 and not (i == nb - 1 and r == 3))  # the last block hands fp16 lo halves to the trunk convolution
                     if r == 3:
-                        kw.update(res2=(ws[0], 0), beta=0.2)  # RRDB.forward: out*0.2 + x (block.py:340-344); ws[0] is also `b`
+                        kw.update(res2=(ws[0], 0, *l8), beta=0.2)  # RRDB.forward: out*0.2 + x (block.py:340-344); ws[0] is also `b`
                 else:
                     nxt = free.pop()
                     taken.append(nxt)

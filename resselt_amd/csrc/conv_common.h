@@ -154,6 +154,44 @@ __device__ __forceinline__ f32x4 widen4(uint2 h, uint2 l) {
 }
 
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// lo halves as 8-bit codes (rsa_conv_params.lo8_flags): four channels of a unit half = one dword.  The code of v = hi + lo is the distance
+// from f32(hi) to v counted in steps of 32 f32 ulps along the f32 bit patterns (sign-magnitude: both have the sign of v), a signed byte:
+//   d = sat16(bits(v) - bits(f32(hi)))     s = low byte of min(sat16(d + 16) >> 5, 127)     v' = as_float(bits(f32(hi)) + (s << 5))
+// |lo| is at most half an fp16 ulp = 2^12 f32 ulps, so s covers it and hi + code keep 19 mantissa bits.  The `min` matters for the tie
+// (+half an ulp: one step short).  Where fp16 is coarser than 2^13 f32 ulps (hi = 0 or subnormal) d saturates and the code is one of
+// 0 .. 127 (hi = 0: d >= 0) or the low byte of a negative number; any of them decodes to within 2^-24 of v, never across zero.
+// hi = +-inf: v' not a number or ~3.4e38, the next layer's hi is not finite either -- the fp16 range guard reads hi planes.
+template <int BYTE>
+__device__ __forceinline__ float lo8_decode(float hf, uint32_t l8) {  // v_bfe_i32 + v_lshl_add_u32
+  int s = BYTE == 3 ? (int)l8 >> 24 : __builtin_amdgcn_sbfe(l8, 8 * BYTE, 8);
+  asm("" : "+v"(s));  // keeps the shift out of the extraction (else: shift, shift, and, add)
+  return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, hf) + (uint32_t)(s << 5));
+}
+__device__ __forceinline__ f32x4 widen4_lo8(uint2 h, uint32_t l8) {  // fp16 hi + code -> f32
+  const f16x2 h0 = __builtin_bit_cast(f16x2, h.x), h1 = __builtin_bit_cast(f16x2, h.y);
+  return (f32x4){lo8_decode<0>((float)h0[0], l8), lo8_decode<1>((float)h0[1], l8), lo8_decode<2>((float)h1[0], l8), lo8_decode<3>((float)h1[1], l8)};
+}
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+// two values -> their codes in the low bytes of two int16 (saturating 32 -> 16 bit pack, then packed 16-bit arithmetic)
+__device__ __forceinline__ s16x2 lo8_encode2(float v0, float v1, uint32_t hi01) {
+  const f16x2 h = __builtin_bit_cast(f16x2, hi01);
+  const int d0 = (int)(__builtin_bit_cast(uint32_t, v0) - __builtin_bit_cast(uint32_t, (float)h[0]));
+  const int d1 = (int)(__builtin_bit_cast(uint32_t, v1) - __builtin_bit_cast(uint32_t, (float)h[1]));
+  const s16x2 d = __builtin_bit_cast(s16x2, __builtin_amdgcn_cvt_pk_i16(d0, d1)), r = {16, 16}, m = {127, 127};
+  return __builtin_elementwise_min(__builtin_elementwise_add_sat(d, r) >> 5, m);
+}
+// (v0 .. v3) -> fp16 hi pairs and the four codes as one dword
+__device__ __forceinline__ void split4_lo8(float v0, float v1, float v2, float v3, uint32_t& hi01, uint32_t& hi23, uint32_t& lo8) {
+  asm("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));  // opaque: see split2
+  const f16x2 ha = {(_Float16)v0, (_Float16)v1}, hb = {(_Float16)v2, (_Float16)v3};
+  hi01 = __builtin_bit_cast(uint32_t, ha);
+  hi23 = __builtin_bit_cast(uint32_t, hb);
+  asm("" : "+v"(hi01), "+v"(hi23));  // one v_cvt_pk_f16_f32 each, widened again below
+  const s16x2 sa = lo8_encode2(v0, v1, hi01), sb = lo8_encode2(v2, v3, hi23);
+  lo8 = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, sb), __builtin_bit_cast(uint32_t, sa), 0x06040200u);  // the low bytes
+}
 
 // Two D fragments of the pixel-tile pair (2k, 2k+1) of one 16-channel tile -> the 16-byte plane units of plane 2*ct + (lg >> 1):
 // the even lane group ends up with the full unit of token tile 2k, the odd one with that of 2k+1 (v_permlane16_swap, as the
@@ -214,7 +252,9 @@ struct GeoLW {
 // block: x5 * 0.2 + x), whose hi halves are still in the ring slots `xslots` (4 bits per 16-channel half chunk) of the LDS array `x_lds` --
 // they are read from there (slot geometry: units per slot / per plane / per halo row) instead of a second time from memory; lo halves come
 // from res1_lo as before.
-template <int NCT, int CTW, int NPT, int OUTK, int AC, int EM = 0, int PF = 0, int XL = 0>
+// L8: the lo halves of the plane residuals / outputs as 8-bit codes (rsa_conv_params.lo8_flags): -1 = as the descriptor's flags say (the generic
+// body), 0 = none, 1 = every lo operand of the launch (the direct instantiation of conv5 inside an RRDBNet trunk: no runtime tests, no spills)
+template <int NCT, int CTW, int NPT, int OUTK, int AC, int EM = 0, int PF = 0, int XL = 0, int L8 = -1>
 __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f32x4 (&acc)[NPT][CTW], int n, int y0, int x0, int slab, int wct,
                                               int wpx, int li, int lg, const uint4* x_lds = nullptr, uint32_t xslots = 0u, int x_slot = 0,
                                               int x_ps = 0, int x_iw = 0) {
@@ -232,6 +272,9 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
   static_assert(EM >= 0 && EM <= 4, "epilogue shape");
   const bool OF16 = G ? p.out_fmt == RSA_PF_F16 : PF == RSA_PF_F16;  // plane format of the outputs / of the plane residuals
   const bool RF16 = G ? p.res_fmt == RSA_PF_F16 : PF == RSA_PF_F16;
+  // lo halves as 8-bit codes (fp16 planes only; wave-uniform)
+  const bool R1L8 = L8 < 0 ? (G && (p.lo8_flags & RSA_LO8_RES1) != 0) : L8 == 1, R2L8 = L8 < 0 ? (G && (p.lo8_flags & RSA_LO8_RES2) != 0) : L8 == 1,
+             OL8 = L8 < 0 ? (G && (p.lo8_flags & RSA_LO8_OUT) != 0) : L8 == 1;
   const bool PRELU = G && p.act == RSA_ACT_PRELU;
   const float lin_slope = p.act == RSA_ACT_NONE ? 1.f : p.act_param;  // EM 1 / 2: act(v) = max(v, v * slope)
 #ifdef RSA_ABL_NOEPI
@@ -292,6 +335,7 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
     const char* r2b = (const char*)p.res2 + (((int64_t)n * p4 + (cbase >> 2)) * HW + pix0) * 16;
     // plane residuals: unit (plane cbase/8 + lg/2, pixel), half lg & 1
     const int64_t runit0 = (int64_t)n * p.res_batch_stride + (int64_t)(cbase >> 3) * p.res_plane_stride + pix0;
+    const int64_t runit8 = (int64_t)n * p.lo8_batch_stride + (int64_t)(cbase >> 3) * p.res_plane_stride + pix0;  // the same unit of an lo8 buffer
     const uint32_t rlane = (uint32_t)(lg >> 1) * (uint32_t)p.res_plane_stride;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -305,13 +349,21 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
       if (R2F && okl) nr2[e] = *(const f32x4*)(r2b + foff);
       if (R1P && okl) {
         const uint2 h = *(const uint2*)((const char*)p.res1_hi + runit0 * 16 + poff);
-        const uint2 l = R1L ? *(const uint2*)((const char*)p.res1_lo + runit0 * 16 + poff) : make_uint2(0u, 0u);
-        nr1[e] = widen(h, l);
+        if (R1L8) {
+          nr1[e] = widen4_lo8(h, *(const uint32_t*)((const char*)p.res1_lo + runit8 * 8 + (poff >> 1)));
+        } else {
+          const uint2 l = R1L ? *(const uint2*)((const char*)p.res1_lo + runit0 * 16 + poff) : make_uint2(0u, 0u);
+          nr1[e] = widen(h, l);
+        }
       }
       if (R2P && okl) {
         const uint2 h = *(const uint2*)((const char*)p.res2_hi + runit0 * 16 + poff);
-        const uint2 l = R2L ? *(const uint2*)((const char*)p.res2_lo + runit0 * 16 + poff) : make_uint2(0u, 0u);
-        nr2[e] = widen(h, l);
+        if (R2L8) {
+          nr2[e] = widen4_lo8(h, *(const uint32_t*)((const char*)p.res2_lo + runit8 * 8 + (poff >> 1)));
+        } else {
+          const uint2 l = R2L ? *(const uint2*)((const char*)p.res2_lo + runit0 * 16 + poff) : make_uint2(0u, 0u);
+          nr2[e] = widen(h, l);
+        }
       }
     }
   };
@@ -334,6 +386,7 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
     const int c0 = cbase + lg * 4;
     const bool cok = (wct * CTW + ct < NCT) && c0 < cout8;
     const int64_t runit0 = (int64_t)n * p.res_batch_stride + (int64_t)(cbase >> 3) * p.res_plane_stride + pix0;
+    const int64_t runit8 = (int64_t)n * p.lo8_batch_stride + (int64_t)(cbase >> 3) * p.res_plane_stride + pix0;
     const uint32_t rlane = (uint32_t)(lg >> 1) * (uint32_t)p.res_plane_stride;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -344,10 +397,16 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
       if (EM == 3) rb2h[slot][e] = rb2l[slot][e] = make_uint2(0u, 0u);
       if (okl) {
         if (!XL) rb1h[slot][e] = *(const uint2*)((const char*)p.res1_hi + runit0 * 16 + poff);  // (XL: read from the ring at its use, below)
-        rb1l[slot][e] = *(const uint2*)((const char*)p.res1_lo + runit0 * 16 + poff);
+        if (R1L8)  // one dword of codes (kept in .x; widened by widen4_lo8)
+          rb1l[slot][e].x = *(const uint32_t*)((const char*)p.res1_lo + runit8 * 8 + (poff >> 1));
+        else
+          rb1l[slot][e] = *(const uint2*)((const char*)p.res1_lo + runit0 * 16 + poff);
         if (EM == 3) {
           rb2h[slot][e] = *(const uint2*)((const char*)p.res2_hi + runit0 * 16 + poff);
-          rb2l[slot][e] = *(const uint2*)((const char*)p.res2_lo + runit0 * 16 + poff);
+          if (R2L8)
+            rb2l[slot][e].x = *(const uint32_t*)((const char*)p.res2_lo + runit8 * 8 + (poff >> 1));
+          else
+            rb2l[slot][e] = *(const uint2*)((const char*)p.res2_lo + runit0 * 16 + poff);
         }
       }
     }
@@ -398,8 +457,10 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
                                  (uint32_t)((wpx * RPW + (pt >> 1) + 1) * x_iw + (pt & 1) * 16 + li + 1);
               rb1h[s % (PD + 1)][e] = *(const uint2*)((const char*)x_lds + u * 16u + (uint32_t)(lg & 1) * 8u);
             }
-            cr1[e] = widen(rb1h[s % (PD + 1)][e], rb1l[s % (PD + 1)][e]);
-            cr2[e] = EM == 3 ? widen(rb2h[EM == 3 ? s % (PD + 1) : 0][e], rb2l[EM == 3 ? s % (PD + 1) : 0][e]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            cr1[e] = R1L8 ? widen4_lo8(rb1h[s % (PD + 1)][e], rb1l[s % (PD + 1)][e].x) : widen(rb1h[s % (PD + 1)][e], rb1l[s % (PD + 1)][e]);
+            cr2[e] = EM != 3 ? (f32x4){0.f, 0.f, 0.f, 0.f}
+                             : (R2L8 ? widen4_lo8(rb2h[EM == 3 ? s % (PD + 1) : 0][e], rb2l[EM == 3 ? s % (PD + 1) : 0][e].x)
+                                     : widen(rb2h[EM == 3 ? s % (PD + 1) : 0][e], rb2l[EM == 3 ? s % (PD + 1) : 0][e]));
           }
         } else {
 #pragma unroll
@@ -495,7 +556,17 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
           if (pvalid_of(pt) && cvalid) {
             const uint32_t uoff = (pllane + lpix_of(pt)) * 16u;
             *(uint4*)(ohb + uoff) = uh;
-            if (OLO) *(uint4*)(olb + uoff) = ul;
+            if (OLO && !OL8) *(uint4*)(olb + uoff) = ul;
+          }
+          if (OLO && OL8) {  // wave-uniform: the residuals as 8-bit codes, 8 bytes per unit (one dword per lane before the exchange)
+            uint32_t q[2], t0, t1;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) split4_lo8(v[e][0], v[e][1], v[e][2], v[e][3], t0, t1, q[e]);
+            const u32x2 l8 = __builtin_amdgcn_permlane16_swap(q[0], q[1], false, false);
+            if (pvalid_of(pt) && cvalid) {
+              const int64_t ounit8 = (int64_t)n * p.lo8_batch_stride + (int64_t)(p.out_plane_off + (cbase >> 3)) * p.out_plane_stride + pix0;
+              *(uint2*)((char*)p.out_lo + ounit8 * 8 + (pllane + lpix_of(pt)) * 8u) = make_uint2(l8.x, l8.y);
+            }
           }
         }
       } else {
@@ -613,7 +684,7 @@ __device__ __forceinline__ void epilogue(const rsa_conv_params& p, const f32x4 (
       return;
     default:
 #ifndef RSA_NO_EM
-      if (OUTK == 0 && p.out_hi != nullptr && p.out_f32 == nullptr && p.res1 == nullptr && p.res2 == nullptr && p.act != RSA_ACT_PRELU &&
+      if (OUTK == 0 && p.out_hi != nullptr && p.out_f32 == nullptr && p.res1 == nullptr && p.res2 == nullptr && p.act != RSA_ACT_PRELU && p.lo8_flags == 0 &&
           (p.cout & 15) == 0 && (p.act == RSA_ACT_NONE || (p.act_param >= 0.f && p.act_param <= 1.f))) {
         // the two shapes of an RRDBNet frame, with the descriptor tests folded (see EM above); wave-uniform choice
         const bool planes_res = p.res1_hi != nullptr && p.res1_lo != nullptr && (p.res2_hi == nullptr || p.res2_lo != nullptr);

@@ -175,6 +175,14 @@ int conv_validate(const rsa_conv_params& p) {
     if (p.out_dtype < RSA_F32 || p.out_dtype > RSA_U8) return set_error(RSA_E_ARG, "conv: bad out_dtype");
     if (p.out_dtype == RSA_U8 && p.out_base != nullptr) return set_error(RSA_E_UNSUPPORTED, "conv: an 8-bit image store takes no base image");
   }
+  if (p.lo8_flags != 0) {
+    if ((p.lo8_flags & ~(RSA_LO8_RES1 | RSA_LO8_RES2 | RSA_LO8_OUT)) || p.reserved_lo8 != 0 || p.lo8_batch_stride < 1)
+      return set_error(RSA_E_ARG, "conv: lo8_flags / lo8_batch_stride");
+    if (((p.lo8_flags & RSA_LO8_RES1) && (p.res1_lo == nullptr || p.res_fmt != RSA_PF_F16)) || ((p.lo8_flags & RSA_LO8_RES2) && (p.res2_lo == nullptr || p.res_fmt != RSA_PF_F16)) ||
+        ((p.lo8_flags & RSA_LO8_OUT) && (p.out_lo == nullptr || p.out_fmt != RSA_PF_F16)))
+      return set_error(RSA_E_ARG, "conv: an lo8 operand needs its lo pointer and fp16 planes");
+    if (p.ksize == 1 && p.cout >= 96 && p.out_nchw == nullptr) return set_error(RSA_E_UNSUPPORTED, "conv: the wide k1 schedule has no lo8 epilogue");
+  }
   if (p.w_layout < RSA_WL_TAPS || p.w_layout > RSA_WL_UPPHASE) return set_error(RSA_E_ARG, "conv: unknown w_layout");
   if (p.w_layout != RSA_WL_TAPS) {  // ring schedule (conv_ring.h): the descriptor carries the K order its weights were packed in
     // (layout 3 stays valid when RSA_CONV_UP2 / the debug override change what rsa_conv_weight_layout would answer now)

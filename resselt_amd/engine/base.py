@@ -69,11 +69,11 @@ def conv_algorithmic_bytes(p: L.ConvParams) -> int:
     total = p.cin_planes * 16 * (2 if p.products == 3 else 1) * px_in
     maps = (p.cout + 3) // 4 * 16 * px_out
     total += maps * sum(1 for r in (p.res1, p.res2, p.out_f32) if r)
-    for hi, lo in ((p.res1_hi, p.res1_lo), (p.res2_hi, p.res2_lo)):  # plane residuals: 2 B / channel per half
-        if hi:
-            total += (p.cout + 7) // 8 * 16 * (2 if lo else 1) * px_out
+    for hi, lo, l8 in ((p.res1_hi, p.res1_lo, p.lo8_flags & L.LO8_RES1), (p.res2_hi, p.res2_lo, p.lo8_flags & L.LO8_RES2)):
+        if hi:  # plane residuals: 2 B / channel per 16-bit half, 1 B / channel for an 8-bit lo half
+            total += (p.cout + 7) // 8 * (16 + (8 if l8 else 16 if lo else 0)) * px_out
     if p.out_hi:
-        total += (p.cout + 7) // 8 * 16 * (2 if p.out_lo else 1) * px_out
+        total += (p.cout + 7) // 8 * (16 + (8 if p.lo8_flags & L.LO8_OUT else 16 if p.out_lo else 0)) * px_out
     if p.out_nchw:
         esize = {L.F32: 4, L.F16: 2, L.BF16: 2, L.U8: 1}[p.out_dtype]
         total += p.cout * esize * px_out * (2 if p.out_base else 1)

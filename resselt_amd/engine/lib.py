@@ -18,6 +18,7 @@ _lib: Optional[C.CDLL] = None
 ACT_NONE, ACT_LRELU, ACT_MISH, ACT_SILU, ACT_GELU, ACT_SPAB_GATE, ACT_PRELU = range(7)
 # enum rsa_dtype
 F32, F16, BF16, U8 = range(4)
+LO8_RES1, LO8_RES2, LO8_OUT = 1, 2, 4  # rsa_conv_params.lo8_flags
 # enum rsa_plane_fmt
 PF_BF16, PF_F16 = range(2)
 E_INTERNAL = -4
@@ -74,6 +75,9 @@ class ConvParams(C.Structure):
         ('out_fmt', C.c_int32),
         ('res_fmt', C.c_int32),
         ('tile_order', C.c_int32),
+        ('lo8_flags', C.c_int32),
+        ('reserved_lo8', C.c_int32),
+        ('lo8_batch_stride', C.c_int64),
     ]
 
 

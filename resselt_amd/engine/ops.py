@@ -121,6 +121,7 @@ def conv_params(
     act_vec: torch.Tensor | None = None,
     out_base: torch.Tensor | None = None,
     out_base_div: int = 0,
+    out_lo8: bool = False,
 ) -> L.ConvParams:
     """Fill one ``rsa_conv_params``. ``H``, ``W`` are the OUTPUT size of the convolution."""
     p = L.ConvParams()
@@ -157,9 +158,16 @@ def conv_params(
     p.beta = beta
     p4 = (wts.cout + 3) // 4
     # a residual is an f32 map, or split planes given as (Planes, first plane): value = hi + lo
+    # (a plane residual may carry a third element 'lo8': its lo halves are read from the buffer's 8-bit lo planes, rsa_conv_params.lo8_flags)
     plane_res = {}
+    lo8_res = {}
     for name, r in (('res1', res1), ('res2', res2)):
         if isinstance(r, tuple):
+            if len(r) == 3:
+                if r[2] != 'lo8':
+                    raise ValueError(f'{name}: the third element of a plane residual must be "lo8"')
+                lo8_res[name] = True
+                r = r[:2]
             pl, plane0 = r
             if (pl.n, pl.h, pl.w) != (x.n, H, W) or plane0 + (wts.cout + 7) // 8 > pl.planes or wts.cout % 8:
                 raise ValueError(f'{name}: plane residual does not match the convolution output')
@@ -174,9 +182,17 @@ def conv_params(
     p.res2 = None if res2 is None or 'res2' in plane_res else res2.data_ptr()
     if len({pl.fmt for pl, _ in plane_res.values()}) > 1:
         raise ValueError('res1 and res2 plane residuals must share their plane format')
+    lo8_strides = set()
     for name, (pl, plane0) in plane_res.items():
         setattr(p, f'{name}_hi', pl.hi_ptr(plane0))
-        setattr(p, f'{name}_lo', pl.lo_ptr(plane0) if pl.has_lo(plane0, (wts.cout + 7) // 8) else None)
+        if lo8_res.get(name):
+            if pl.fmt != PF_F16 or not pl.has_lo8(plane0, (wts.cout + 7) // 8):
+                raise ValueError(f'{name}: lo8 needs fp16 planes with an 8-bit lo buffer over the residual planes')
+            setattr(p, f'{name}_lo', pl.lo8_ptr(plane0))
+            p.lo8_flags |= L.LO8_RES1 if name == 'res1' else L.LO8_RES2
+            lo8_strides.add(pl.lo8_batch_stride)
+        else:
+            setattr(p, f'{name}_lo', pl.lo_ptr(plane0) if pl.has_lo(plane0, (wts.cout + 7) // 8) else None)
         p.res_plane_stride, p.res_batch_stride = pl.plane_stride, pl.batch_stride
         p.res_fmt = pl.fmt
     p.out_f32 = None if out_f32 is None else out_f32.data_ptr()
@@ -186,11 +202,24 @@ def conv_params(
             raise ValueError('output planes do not match the convolution output')
         p.out_hi = out.hi_ptr()
         # lo halves are written only where the buffer keeps them for EVERY plane this layer writes (see tensors.Planes.empty: lo_planes)
-        p.out_lo = out.lo_ptr() if out.has_lo(out_plane_off, nplanes_out) else None
+        if out_lo8:
+            if out.fmt != PF_F16 or not out.has_lo8(out_plane_off, nplanes_out):
+                raise ValueError('out_lo8 needs fp16 output planes with an 8-bit lo buffer over the written planes')
+            p.out_lo = out.lo8_ptr()
+            p.lo8_flags |= L.LO8_OUT
+            lo8_strides.add(out.lo8_batch_stride)
+        else:
+            p.out_lo = out.lo_ptr() if out.has_lo(out_plane_off, nplanes_out) else None
         p.out_fmt = out.fmt
         p.out_plane_off = out_plane_off
         p.out_plane_stride = out.plane_stride
         p.out_batch_stride = out.batch_stride
+    if out_lo8 and out is None:
+        raise ValueError('out_lo8 without output planes')
+    if p.lo8_flags:
+        if len(lo8_strides) != 1:
+            raise ValueError('the lo8 operands of a launch must share their batch stride')
+        p.lo8_batch_stride = lo8_strides.pop()
     p.pixel_shuffle = pixel_shuffle
     p.out_scale = out_scale
     if out_nchw is not None:

@@ -25,6 +25,10 @@ _PF_DTYPE = {PF_BF16: torch.bfloat16, PF_F16: torch.float16}
 class Planes:
     hi: torch.Tensor  # [N, P, H, W, 8] bf16 or fp16 (dense, or the first P planes of a [N, P + lo_planes, ...] allocation)
     lo: torch.Tensor | None  # [N, lo_planes <= P, H, W, 8] of the same dtype, or None (one-product consumers only)
+    # Round 4: the lo halves of the first planes as 8-bit codes (`lo8_encode`), [N, lo8_planes, H, W, 8] uint8 = 8-byte units: the residual stream of
+    # RRDBNet's dense blocks under 'mixed' (3 bytes per channel; rsa_conv_params.lo8_flags).  Independent of ``lo``: a buffer may carry both (the
+    # first and the last block of a trunk exchange fp16 lo halves with the three-product layers around it).
+    lo8: torch.Tensor | None = None
 
     @staticmethod
     def empty(n: int, planes: int, h: int, w: int, device, with_lo: bool = True, fmt: int = PF_BF16, lo_planes: int | None = None) -> 'Planes':
@@ -46,7 +50,7 @@ class Planes:
         return 0 if self.lo is None else self.lo.shape[1]
 
     def nbytes(self) -> int:
-        return (self.hi.shape[1] + self.lo_planes) * self.hi.shape[0] * self.h * self.w * 16
+        return (self.hi.shape[1] + self.lo_planes) * self.hi.shape[0] * self.h * self.w * 16 + (0 if self.lo8 is None else self.lo8.numel())
 
     @property
     def n(self) -> int:
@@ -83,6 +87,21 @@ class Planes:
     def has_lo(self, plane0: int, nplanes: int) -> bool:
         """Whether planes [plane0, plane0 + nplanes) all carry lo halves."""
         return self.lo is not None and plane0 + nplanes <= self.lo.shape[1]
+
+    def with_lo8(self, planes: int) -> 'Planes':
+        """Attach an 8-bit lo buffer for the first ``planes`` planes (see ``lo8``)."""
+        self.lo8 = torch.empty((self.n, planes, self.h, self.w, 8), dtype=torch.uint8, device=self.hi.device)
+        return self
+
+    def has_lo8(self, plane0: int, nplanes: int) -> bool:
+        return self.lo8 is not None and plane0 + nplanes <= self.lo8.shape[1]
+
+    def lo8_ptr(self, plane: int = 0) -> int:
+        return self.lo8.data_ptr() + plane * self.plane_stride * 8
+
+    @property
+    def lo8_batch_stride(self) -> int:  # units of 8 bytes
+        return self.lo8.stride(0) // 8
 
 
 class PlaneRows:
@@ -122,9 +141,29 @@ def empty_f32map(n: int, channels: int, h: int, w: int, device) -> torch.Tensor:
 # ---- reference conversions (torch ops; used by tests and debugging, not by the forward path) ----
 
 
-def planes_to_nchw(p: Planes, channels: int) -> torch.Tensor:
+def lo8_encode(v: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """f32 -> (fp16 hi, 8-bit code of v - hi): the distance from f32(hi) to v in steps of 32 f32 ulps along the bit patterns, a signed byte
+    stored in a uint8 tensor -- `lo8_encode2` of csrc/conv_common.h, operation for operation (the distance saturates to 16 bits, so the code
+    is exact whenever hi is a normal fp16 number; with hi = 0 or subnormal it decodes to within 2^-24 of the value)."""
+    hi = v.to(torch.float16)
+    d = v.contiguous().view(torch.int32) - hi.to(torch.float32).view(torch.int32)  # same sign bit in both: the difference of the magnitudes
+    d = (d.clamp(-32768, 32767) + 16).clamp(max=32767)
+    return hi, ((d >> 5).clamp(max=127) & 0xFF).to(torch.uint8)
+
+
+def lo8_decode(hi: torch.Tensor, code: torch.Tensor) -> torch.Tensor:
+    """(fp16 hi, code) -> f32, as `lo8_decode` in csrc/conv_common.h."""
+    return (hi.to(torch.float32).contiguous().view(torch.int32) + (code.contiguous().view(torch.int8).to(torch.int32) << 5)).view(torch.float32)
+
+
+def planes_to_nchw(p: Planes, channels: int, lo8: bool = False) -> torch.Tensor:
+    """``lo8``: decode the 8-bit lo buffer instead of adding the 16-bit one."""
     v = p.hi.to(torch.float32)
-    if p.lo is not None:
+    if lo8:
+        v = v.clone()
+        k = p.lo8.shape[1]
+        v[:, :k] = lo8_decode(p.hi[:, :k], p.lo8)
+    elif p.lo is not None:
         v = v.clone()
         v[:, : p.lo.shape[1]] += p.lo.to(torch.float32)
     n, pl, h, w, _ = v.shape

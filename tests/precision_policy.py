@@ -57,7 +57,11 @@ def emulate(policy, stream_dtype: torch.dtype | None = None):
 
     def rdb(sd, prefix, x, plus=False):
         y = orig_rdb(sd, prefix, x, plus)
-        if stream_dtype is not None:
+        if stream_dtype == 'lo8':  # round 4: fp16 hi + 8-bit code of the lo half (rsa_conv_params.lo8_flags)
+            from resselt_amd.engine.tensors import lo8_decode, lo8_encode
+
+            y = lo8_decode(*lo8_encode(y))
+        elif stream_dtype is not None:
             hi, lo = _halves(y, stream_dtype)
             y = hi + lo
         return y

@@ -335,3 +335,80 @@ def test_span_family_layer_direct_epilogue(device, act, out_lo):
     # hi only: the value rounded to fp16; hi + lo: 22 bits; the activation functions run on hardware exp / rcp (1 ulp each)
     tol = (2.0**-11 * 1.01 if not out_lo else 2e-6) * scale + 3e-6 * scale
     assert (got - ref).abs().max().item() <= tol, (got - ref).abs().max().item()
+
+
+
+
+
+
+@pytest.mark.parametrize('case', ['all_lo8', 'last_block', 'one_residual', 'first_layer'])
+def test_residual_stream_with_8bit_lo_halves(device, case):
+    """Round 4: the lo halves of the fp16 residual stream as 8-bit codes (offsets from hi in 1/254 ulp; rsa_conv_params.lo8_flags).  conv5 of a dense block with both
+    residuals and its output in that form (the direct instantiation `XRES 4`), the last block of a trunk (8-bit lo in, fp16 lo out: the generic
+    epilogue), one residual only, and a first layer (3 -> 64 on the chunk-barrier kernel) that writes hi + 8-bit lo planes beside its f32 map."""
+    n, h, w, pf, pg = 1, 37, 70, 8, 4
+    g = torch.Generator().manual_seed(15)
+
+    def stream(seed):  # a 64-channel map as the engine stores it (fp16 hi + 8-bit code), with zeros, fp16 subnormals and powers of two in it
+        v = _rand((n, 64, h, w), seed)
+        v[:, :, 0, :8] = torch.tensor([0.0, 1e-7, -3e-6, 6.1e-5, 0.25, -0.5, 0.24999, 1.0001])
+        v[:, :, 1, :6] = torch.tensor([1e-9, -1e-9, 2.9e-8, -2.5e-8, 1.0 + 2.0**-11, -3.0 - 2.0**-9])  # hi = +-0 with v != 0; ties
+        hi, code = tensors.lo8_encode(v)
+        return hi, code, tensors.lo8_decode(hi, code)
+
+    def fill(pl, hc):  # hi planes + 8-bit lo planes of the first 8 planes
+        hi, code = hc[:2]
+        pl.hi[:, :pf] = hi.reshape(n, pf, 8, h, w).permute(0, 1, 3, 4, 2).to(device)
+        pl.lo8.copy_(code.reshape(n, pf, 8, h, w).permute(0, 1, 3, 4, 2).to(device))
+
+    if case == 'first_layer':
+        x = _rand((n, 3, h, w), 1)
+        wt, b = _rand((64, 3, 3, 3), 2, 0.2), _rand((64,), 3, 0.1)
+        wts = ops.ConvWeights.from_oihw(wt, b, 3, device=device)
+        xin = tensors.nchw_to_planes(x.to(device), True)
+        out = tensors.Planes.empty(n, pf + 4 * pg, h, w, device, True, PF_F16, lo_planes=pf).with_lo8(pf)
+        of32 = tensors.empty_f32map(n, 64, h, w, device)
+        p = ops.conv_params(wts, xin, h, w, out=out, out_f32=of32, out_lo8=True)
+        assert p.lo8_flags == L.LO8_OUT and 'XRES' not in L.conv_kernel_name(p)
+        ops.run_convs([p], device)
+        torch.cuda.synchronize()
+        ref = tensors.f32map_to_nchw(of32, 64).cpu()  # the kernel's own f32 result: the planes must be its (hi, code) split, bit for bit
+        hi, code = tensors.lo8_encode(ref)
+        assert torch.equal(tensors.planes_to_nchw(tensors.Planes(out.hi[:, :pf].contiguous(), None), 64).cpu(), hi.float())
+        assert torch.equal(out.lo8.cpu().permute(0, 1, 4, 2, 3).reshape(n, 64, h, w), code)
+        got = tensors.planes_to_nchw(tensors.Planes(out.hi[:, :pf].contiguous(), None, out.lo8), 64, lo8=True).cpu()
+        assert (got - ref).abs().max().item() <= 2.0**-19 * ref.abs().max().item()
+        return
+    xs, r0s = stream(5), stream(6)
+    x, r0v = xs[2], r0s[2]
+    ws = tensors.Planes.empty(n, pf + 4 * pg, h, w, device, True, PF_F16, lo_planes=pf).with_lo8(pf)
+    ws.hi.zero_()
+    fill(ws, xs)
+    ws.hi[:, pf:] = tensors.nchw_to_planes(_rand((n, 128, h, w), 7).to(device), False, PF_F16).hi  # the growth channels x1 .. x4
+    r0 = tensors.Planes.empty(n, pf + 4 * pg, h, w, device, True, PF_F16, lo_planes=pf).with_lo8(pf)
+    fill(r0, r0s)
+    out = tensors.Planes.empty(n, pf + 4 * pg, h, w, device, True, PF_F16, lo_planes=pf).with_lo8(pf)
+    wt = (torch.rand((64, 192, 3, 3), generator=g) * 2 - 1) / (192 * 9) ** 0.5
+    b = (torch.rand((64,), generator=g) * 2 - 1) * 0.1
+    wts = ops.ConvWeights.from_oihw(wt, b, 1, device=device, fmt=PF_F16)
+    cat = tensors.planes_to_nchw(tensors.Planes(ws.hi, None), 192).cpu()  # what the multiply reads: hi planes only
+    y = _conv(cat, _h(wt), b)
+    two = case != 'one_residual'
+    ref = y * 0.2 + x
+    if two:
+        ref = ref * 0.2 + r0v
+    kw = dict(res2=(r0, 0, 'lo8'), beta=0.2) if two else {}
+    p = ops.conv_params(wts, ws, h, w, cin_planes=24, res1=(ws, 0, 'lo8'), alpha=0.2, out=out, out_lo8=case != 'last_block', **kw)
+    name = L.conv_kernel_name(p)
+    assert ('XRES' in name) == (case != 'last_block'), name  # mixed lo formats take the generic epilogue
+    ops.run_convs([p], device)
+    torch.cuda.synchronize()
+    assert L.ring_aborts() == 0
+    L.check_status('test')
+    if case == 'last_block':
+        got = tensors.planes_to_nchw(tensors.Planes(out.hi[:, :pf].contiguous(), out.lo[:, :pf].contiguous()), 64).cpu()
+        tol = 2e-5
+    else:
+        got = tensors.planes_to_nchw(tensors.Planes(out.hi[:, :pf].contiguous(), None, out.lo8), 64, lo8=True).cpu()
+        tol = 2.0**-19 * ref.abs().max().item() + 2e-5  # the coding's step is 2^-19 of the value; 2e-5: summation order of a 1728-term sum of fp16 products
+    assert (got - ref).abs().max().item() <= tol, (got - ref).abs().max().item()

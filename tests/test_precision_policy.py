@@ -46,9 +46,11 @@ def test_mixed_policy_meets_the_bar_on_rrdbnet23():
     torch.set_num_threads(8)
     sd = synth.rrdbnet_state_dict(nb=23, seed=0)
     x = synth.synth_input((1, 3, 1080, 1920), seed=0)[:, :, 400:528, 800:928].contiguous()
-    e = _errors(sd, x, {'mixed': (P.rrdbnet_auto, torch.float16), 'fp16': (P.uniform('fp16'), None), 'bf16x3': (P.uniform('bf16x3'), torch.bfloat16)})
+    e = _errors(sd, x, {'mixed': (P.rrdbnet_auto, 'lo8'), 'mixed_fp16_lo': (P.rrdbnet_auto, torch.float16), 'fp16': (P.uniform('fp16'), None),
+                        'bf16x3': (P.uniform('bf16x3'), torch.bfloat16)})  # fmt: skip
     print(e)
-    assert e['mixed'] <= 2e-4 and e['bf16x3'] <= 1e-4
+    # round 4: the stream's lo halves are 8-bit codes (hi fp16 + 8 more mantissa bits: 19); round 3 kept fp16 lo halves (22 bits): same error
+    assert e['mixed'] <= 2e-4 and e['mixed_fp16_lo'] <= 2e-4 and e['bf16x3'] <= 1e-4
     assert e['fp16'] > 1e-3  # one product everywhere does NOT meet north_star's bar: the reason the policy is per layer
 
 
@@ -56,9 +58,9 @@ def test_mixed_policy_on_heavy_tailed_weights():
     torch.set_num_threads(8)
     sd = synth.rrdbnet_heavy_tailed_state_dict(nb=23, seed=4)
     x = synth.synth_input((1, 3, 96, 112), seed=4)
-    e = _errors(sd, x, {'mixed': (P.rrdbnet_auto, torch.float16)})
+    e = _errors(sd, x, {'mixed': (P.rrdbnet_auto, 'lo8'), 'mixed_fp16_lo': (P.rrdbnet_auto, torch.float16)})
     print(e)
-    assert e['mixed'] <= 2e-4
+    assert e['mixed'] <= 2e-4 and e['mixed_fp16_lo'] <= 2e-4
 
 
 def test_span_mixed_policy_on_spanplus_x4():
@@ -100,7 +102,9 @@ def test_transformer_policies_name_the_one_product_layers():
     assert HAT.layer_policy('layers.1.residual_group.overlap_attn.qkv') == one and HAT.layer_policy('layers.1.conv') == three
     d = 'layers.0.blocks.1'
     assert DAT.layer_policy(f'{d}.attn.qkv') == one and DAT.layer_policy(f'{d}.ffn.fc1') == one
-    assert DAT.layer_policy(f'{d}.attn.proj') == three and DAT.layer_policy(f'{d}.ffn.fc2') == three and DAT.layer_policy('conv_first') == three
+    # round 4: DAT's whole transformer body is on fp16 planes (proj and fc2 too); the 3x3 convolutions keep three products
+    assert DAT.layer_policy(f'{d}.attn.proj') == one and DAT.layer_policy(f'{d}.ffn.fc2') == one
+    assert DAT.layer_policy('conv_first') == three and DAT.layer_policy('layers.0.conv') == three and DAT.layer_policy('conv_after_body') == three
     sd = synth.drct_state_dict(num_layers=1, embed_dim=60, gc=16, window=8)
     import resselt_amd
 
