@@ -373,6 +373,10 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
 #ifndef RSA_EPI_PD
 #define RSA_EPI_PD 3
 #endif
+#ifndef RSA_EPI_C5
+#define RSA_EPI_C5 0  // 1: conv5's arithmetic without the per-lane selects and the (identity) activation, 2: the same on value pairs (v_pk_fma_f32).
+                      // Both measured SLOWER than the select form on the frame (+0.6 % / +4.6 %: profiles/r04_t_conv5_epilogue_forms_ab.txt)
+#endif
 #ifndef RSA_EPI_PDX
 #define RSA_EPI_PDX 1  // XL: the hi halves come from LDS at their use, only lo halves (and the second residual) are fetched ahead; one step
                        // ahead measured best (deeper: the raw values spill; profiles/r03_i_conv5_epilogue_prefetch.txt)
@@ -481,7 +485,37 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
         ok[e] = pvalid_of(pt) && cvalid;
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[e][r] = acc[pt][ct][r] + bias[r];
-        if (OUTK == 0) {
+        if (OUTK == 0 && RSA_EPI_C5 && (EM == 2 || EM == 3)) {
+          // conv5 of a residual dense block: (acc + bias [LeakyReLU]) * alpha + r1 [* beta + r2].  Lanes outside the map hold zeros for the
+          // residuals and store nothing: no per-lane selects; no activation (conv5 has none): a wave-uniform skip of its two instructions per value.
+#if RSA_EPI_C5 == 2  // value pairs (v_pk_fma_f32): fewer instructions, but the register pairs cost moves and spills (A/B: profiles/r04_t_*)
+          f32x2 a = {v[e][0], v[e][1]}, b = {v[e][2], v[e][3]};
+          if (p.act != RSA_ACT_NONE) {
+            a = __builtin_elementwise_max(a, a * lin_slope);
+            b = __builtin_elementwise_max(b, b * lin_slope);
+          }
+          const f32x2 al = {p.alpha, p.alpha};
+          a = __builtin_elementwise_fma(a, al, (f32x2){cr1[e][0], cr1[e][1]});
+          b = __builtin_elementwise_fma(b, al, (f32x2){cr1[e][2], cr1[e][3]});
+          if (EM == 3) {
+            const f32x2 be = {p.beta, p.beta};
+            a = __builtin_elementwise_fma(a, be, (f32x2){cr2[e][0], cr2[e][1]});
+            b = __builtin_elementwise_fma(b, be, (f32x2){cr2[e][2], cr2[e][3]});
+          }
+          v[e][0] = a[0], v[e][1] = a[1], v[e][2] = b[0], v[e][3] = b[1];
+#else
+          if (p.act != RSA_ACT_NONE) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[e][r] = fmaxf(v[e][r], v[e][r] * lin_slope);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[e][r] = v[e][r] * p.alpha + cr1[e][r];
+          if (EM == 3) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[e][r] = v[e][r] * p.beta + cr2[e][r];
+          }
+#endif
+        } else if (OUTK == 0) {
           const uint32_t foff = (f32lane + lpix_of(pt)) * 16u;
           if (AC == AC_GATE) {
             const f32x4 rr = cr1[e];
@@ -520,11 +554,16 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
       }
       if (OUTK == 0) {
         if (OHI) {  // wave-uniform: every lane takes part in the exchange
-          uint32_t h[2][2], l[2][2];
+          uint32_t h[2][2], l[2][2], q8[2];
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
-            split2_rt(OF16, v[e][0], v[e][1], h[e][0], l[e][0]);
-            split2_rt(OF16, v[e][2], v[e][3], h[e][1], l[e][1]);
+            if (OLO && OL8) {  // hi halves and the 8-bit codes of the lo halves from one pass over the values
+              split4_lo8(v[e][0], v[e][1], v[e][2], v[e][3], h[e][0], h[e][1], q8[e]);
+              l[e][0] = l[e][1] = 0u;
+            } else {
+              split2_rt(OF16, v[e][0], v[e][1], h[e][0], l[e][0]);
+              split2_rt(OF16, v[e][2], v[e][3], h[e][1], l[e][1]);
+            }
           }
           const int odd = lg & 1;  // odd lanes keep pixel-tile 2k+1 and give away their half of 2k; even lanes the reverse
           // v_permlane16_swap_b32 a, b swaps the odd 16-lane rows of a with the even rows of b: with a = this lane's half of pixel-tile
@@ -559,10 +598,7 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
             if (OLO && !OL8) *(uint4*)(olb + uoff) = ul;
           }
           if (OLO && OL8) {  // wave-uniform: the residuals as 8-bit codes, 8 bytes per unit (one dword per lane before the exchange)
-            uint32_t q[2], t0, t1;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) split4_lo8(v[e][0], v[e][1], v[e][2], v[e][3], t0, t1, q[e]);
-            const u32x2 l8 = __builtin_amdgcn_permlane16_swap(q[0], q[1], false, false);
+            const u32x2 l8 = __builtin_amdgcn_permlane16_swap(q8[0], q8[1], false, false);
             if (pvalid_of(pt) && cvalid) {
               const int64_t ounit8 = (int64_t)n * p.lo8_batch_stride + (int64_t)(p.out_plane_off + (cbase >> 3)) * p.out_plane_stride + pix0;
               *(uint2*)((char*)p.out_lo + ounit8 * 8 + (pllane + lpix_of(pt)) * 8u) = make_uint2(l8.x, l8.y);

@@ -9,7 +9,8 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 od=$root/build/obj_$name; mkdir -p $od
 pids=()
 for f in $files; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c $flags -I$root/include -I$root/resselt_amd/csrc $root/resselt_amd/csrc/$f.hip -o $od/$f.o &
+  slp=""; case $f in conv_inst_ring*) slp="-fno-slp-vectorize";; esac   # as resselt_amd/build.py compiles these units
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $slp -std=c++17 -fPIC -c $flags -I$root/include -I$root/resselt_amd/csrc $root/resselt_amd/csrc/$f.hip -o $od/$f.o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
