@@ -34,10 +34,25 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // planes in registers (up to LN_MAXP planes = 8*4*LN_MAXP = 256 channels), so the f32 map is read exactly once; mean and the
 // centred variance are each closed by a 4-way reduction through LDS.
 constexpr int LN_MAXP = 8;
+#ifndef LN_WAVES
+#define LN_WAVES 4  // waves per SIMD the register allocation must allow (left alone the compiler took 233 VGPRs: two workgroups per CU)
+#endif
+constexpr int LN_LDS_C = 1024;  // gamma / beta staged in LDS up to this many channels
 
 template <bool IN_REGS>
-__global__ __launch_bounds__(256) void layernorm_kernel(const rsa_layernorm_params p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LN_WAVES, 8))) void layernorm_kernel(const rsa_layernorm_params p) {
   __shared__ float s_red[2][4][64];
+  // gamma / beta of every channel in LDS, zeros beyond C: the per-channel global loads of the output phase (a lane-dependent channel index, so
+  // vector loads, each waited for: 48 round trips per wave) were 2/3 of the kernel's time (profiles/r04_u_layernorm_probe.txt)
+  __shared__ __attribute__((aligned(16))) float s_gb[2][LN_LDS_C];
+  const bool gb_lds = IN_REGS || p.C <= LN_LDS_C;  // (IN_REGS: C <= 32 * LN_MAXP)
+  if (gb_lds) {
+    for (int c = threadIdx.x; c < ((p.C + 7) & ~7); c += 256) {
+      s_gb[0][c] = c < p.C ? p.gamma[c] : 0.f;
+      s_gb[1][c] = c < p.C ? p.beta[c] : 0.f;
+    }
+    __syncthreads();
+  }
   const int64_t HW = (int64_t)p.H * p.W;
   const int64_t total = (int64_t)p.batch * HW;
   const int p4 = (p.C + 3) >> 2;
@@ -113,11 +128,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const rsa_layernorm_para
     const float rstd = rsqrtf((s_red[1][0][lane] + s_red[1][1][lane] + s_red[1][2][lane] + s_red[1][3][lane]) * inv_c + p.eps);
     auto emit = [&](int pl, const f32x4 a, const f32x4 b) {
       float y[8];
+      if (gb_lds) {
+        const f32x4 g0 = *(const f32x4*)&s_gb[0][pl * 8], g1 = *(const f32x4*)&s_gb[0][pl * 8 + 4];
+        const f32x4 b0 = *(const f32x4*)&s_gb[1][pl * 8], b1 = *(const f32x4*)&s_gb[1][pl * 8 + 4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c = pl * 8 + j;
-        const float t = j < 4 ? a[j] : b[j - 4];
-        y[j] = (c < p.C) ? (t - mean) * rstd * p.gamma[c] + p.beta[c] : 0.f;
+        for (int j = 0; j < 4; ++j) {
+          y[j] = (a[j] - mean) * rstd * g0[j] + b0[j];  // channels beyond C: gamma = beta = 0
+          y[4 + j] = (b[j] - mean) * rstd * g1[j] + b1[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = pl * 8 + j;
+          const float t = j < 4 ? a[j] : b[j - 4];
+          y[j] = (c < p.C) ? (t - mean) * rstd * p.gamma[c] + p.beta[c] : 0.f;
+        }
       }
       if (p.out_f32 != nullptr) {
         if (pl * 2 < p4) ((f32x4*)p.out_f32)[((int64_t)n * p4 + pl * 2) * HW + pix] = (f32x4){y[0], y[1], y[2], y[3]};
@@ -151,6 +176,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const rsa_layernorm_para
         for (int k = 0; k < LN_MAXP; ++k) {
           const int pl = wave + 4 * k;
           if (pl < planes) emit(pl, v[k][0], v[k][1]);
+          __builtin_amdgcn_sched_barrier(0);  // one plane at a time: hoisting every plane's gamma / beta reads cost 120 registers
         }
       } else {
         for (int pl = wave; pl < planes; pl += 4) {
@@ -159,6 +185,133 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const rsa_layernorm_para
           if (pl * 2 + 1 < p4) b = x[(int64_t)(pl * 2 + 1) * HW];
           emit(pl, a, b);
         }
+      }
+    }
+  }
+}
+
+// two values -> packed hi pair and packed lo pair of a plane format (as conv_common.h::split2; the fp16 form is opaque to the contraction pass)
+template <int FMT>
+__device__ __forceinline__ void ln_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  if constexpr (FMT == RSA_PF_F16) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+    asm("" : "+v"(a), "+v"(b));
+    const f16x2 h = {(_Float16)a, (_Float16)b};
+    hi = __builtin_bit_cast(uint32_t, h);
+    const f16x2 l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+    lo = __builtin_bit_cast(uint32_t, l);
+  } else {
+    const bf16x2 h = {(__bf16)a, (__bf16)b};
+    hi = __builtin_bit_cast(uint32_t, h);
+    const bf16x2 l = {(__bf16)(a - __builtin_bit_cast(float, hi << 16)), (__bf16)(b - __builtin_bit_cast(float, hi & 0xffff0000u))};
+    lo = __builtin_bit_cast(uint32_t, l);
+  }
+}
+
+// C <= 32 * MAXP (MAXP 8: every LayerNorm of the SwinIR / HAT / DAT bodies; 12: DRCT's dense blocks, up to 308 channels), round 4: the same work split with everything wave-uniform kept in scalar
+// registers -- the wave id through readfirstlane, 64-token blocks that never straddle two images (so the image index and every plane base
+// are uniform and a lane's address is base + 16 * pixel), whole-plane validity as scalar branches -- and gamma / beta read from LDS.
+// 76 VGPRs (the first form: 233, two workgroups per CU, and 48 waited-for gamma / beta loads per wave): 121 -> 45 us for 180 channels at 512^2.
+template <int MAXP>
+__global__ __launch_bounds__(256) void layernorm_regs_kernel(const rsa_layernorm_params p) {
+  __shared__ float s_red[2][4][64];
+  __shared__ __attribute__((aligned(16))) float s_gb[2][32 * MAXP];
+  bool staged = false;
+  const uint32_t HW = (uint32_t)p.H * (uint32_t)p.W;
+  const int p4 = (p.C + 3) >> 2;
+  const int planes = (p.C + 7) >> 3;
+  const float inv_c = 1.f / (float)p.C;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t bpi = (HW + 63u) >> 6;  // blocks per image
+  const uint32_t nblk = bpi * (uint32_t)p.batch;
+  for (uint32_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const uint32_t n = blk / bpi;
+    const uint32_t pix = (blk - n * bpi) * 64u + (uint32_t)lane;
+    const bool live = pix < HW;
+    const uint32_t loff = (live ? pix : 0u) * 16u;  // byte offset of this lane's token inside a group plane of the f32 map / a 16-byte-unit plane
+    const char* xb = (const char*)p.x_f32 + (size_t)n * p4 * HW * 16;
+    f32x4 v[MAXP][2];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int g = (wave + 4 * k) * 2 + h;  // uniform
+        v[k][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (g < p4) {
+          v[k][h] = *(const f32x4*)(xb + (size_t)g * HW * 16 + loff);
+          if (g * 4 + 3 >= p.C) {  // the last group of a C that is not a multiple of 4
+#pragma unroll
+            for (int r = 1; r < 4; ++r)
+              if (g * 4 + r >= p.C) v[k][h][r] = 0.f;
+          }
+        }
+      }
+    if (!staged) {  // behind the loads of the first block, in front of the first barrier: its latency hides under theirs
+#pragma unroll
+      for (int c = threadIdx.x; c < 32 * MAXP; c += 256) {
+        const float gv = c < p.C ? p.gamma[c] : 0.f, bv = c < p.C ? p.beta[c] : 0.f;  // zeros beyond C: padded channels come out as 0
+        s_gb[0][c] = gv;
+        s_gb[1][c] = bv;
+      }
+      staged = true;
+    }
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) sum += (v[k][h][0] + v[k][h][1]) + (v[k][h][2] + v[k][h][3]);
+    s_red[0][wave][lane] = sum;
+    __syncthreads();
+    const float mean = (s_red[0][0][lane] + s_red[0][1][lane] + s_red[0][2][lane] + s_red[0][3][lane]) * inv_c;
+    float var = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int g = (wave + 4 * k) * 2 + h;
+        if (g < p4) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float d = v[k][h][r] - mean;
+            var += (g * 4 + r < p.C) ? d * d : 0.f;  // uniform test
+          }
+        }
+      }
+    s_red[1][wave][lane] = var;
+    __syncthreads();  // also orders the next iteration's s_red[0] writes after this iteration's reads
+    const float rstd = rsqrtf((s_red[1][0][lane] + s_red[1][1][lane] + s_red[1][2][lane] + s_red[1][3][lane]) * inv_c + p.eps);
+    const float nm = -mean * rstd;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      const int pl = wave + 4 * k;  // uniform
+      if (pl >= planes) break;
+      const f32x4 g0 = *(const f32x4*)&s_gb[0][pl * 8], g1 = *(const f32x4*)&s_gb[0][pl * 8 + 4];
+      const f32x4 b0 = *(const f32x4*)&s_gb[1][pl * 8], b1 = *(const f32x4*)&s_gb[1][pl * 8 + 4];
+      float y[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        y[j] = (v[k][0][j] * rstd + nm) * g0[j] + b0[j];
+        y[4 + j] = (v[k][1][j] * rstd + nm) * g1[j] + b1[j];
+      }
+      if (!live) continue;
+      if (p.out_f32 != nullptr) {
+        char* ob = (char*)p.out_f32 + ((size_t)n * p4 + (size_t)pl * 2) * HW * 16 + loff;
+        if (pl * 2 < p4) *(f32x4*)ob = (f32x4){y[0], y[1], y[2], y[3]};
+        if (pl * 2 + 1 < p4) *(f32x4*)(ob + (size_t)HW * 16) = (f32x4){y[4], y[5], y[6], y[7]};
+      }
+      if (p.out_hi != nullptr) {
+        uint32_t h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (p.out_fmt == RSA_PF_F16)
+            ln_split2<RSA_PF_F16>(y[2 * j], y[2 * j + 1], h[j], l[j]);
+          else
+            ln_split2<RSA_PF_BF16>(y[2 * j], y[2 * j + 1], h[j], l[j]);
+        }
+        const size_t unit = ((size_t)n * p.out_batch_stride + (size_t)pl * p.out_plane_stride) * 16 + loff;
+        *(uint4*)((char*)p.out_hi + unit) = make_uint4(h[0], h[1], h[2], h[3]);
+        if (p.out_lo != nullptr) *(uint4*)((char*)p.out_lo + unit) = make_uint4(l[0], l[1], l[2], l[3]);
       }
     }
   }
@@ -394,7 +547,14 @@ extern "C" int rsa_layernorm(const rsa_layernorm_params* p, void* stream) {
   const int64_t total = (int64_t)p->batch * p->H * p->W;
   int64_t g = (total + 63) / 64;  // one 256-thread workgroup per 64 tokens
   if (g > 256 * 32) g = 256 * 32;
-  if (p->C <= 32 * LN_MAXP)
+  if (p->C <= 32 * 12 && (int64_t)p->H * p->W < (1ll << 27)) {
+    g = (int64_t)p->batch * (((int64_t)p->H * p->W + 63) / 64);  // blocks of 64 tokens of ONE image
+    if (g > 256 * 32) g = 256 * 32;
+    if (p->C <= 32 * LN_MAXP)
+      hipLaunchKernelGGL(layernorm_regs_kernel<LN_MAXP>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, *p);
+    else
+      hipLaunchKernelGGL(layernorm_regs_kernel<12>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, *p);
+  } else if (p->C <= 32 * LN_MAXP)
     hipLaunchKernelGGL(layernorm_kernel<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, *p);
   else
     hipLaunchKernelGGL(layernorm_kernel<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, *p);
