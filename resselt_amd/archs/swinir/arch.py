@@ -53,43 +53,58 @@ def shift_attn_mask(img_size: int, window: int) -> torch.Tensor:
     return torch.where(d != 0, torch.full_like(d, -100.0), torch.zeros_like(d))
 
 
+_FRAG_LUT: dict = {}
+
+
+def _fragment_lut(index: torch.Tensor, window: int, order: str) -> torch.Tensor:
+    """Row of the bias table each accumulator element reads (-1: a padded key -> -1e30; -2: a padded query -> 0), in the order of
+    `bias_fragments` ('32') or `bias_fragments16` ('16').  It depends on the window and on the index buffer only, which every layer of a
+    network shares: built once and reused while the index has the same content (the per-layer gathers were 0.2 s of a SwinIR-L cold
+    start: 54 layers x 5 indexing operations)."""
+    key = (order, window, str(index.device))
+    hit = _FRAG_LUT.get(key)
+    if hit is not None and hit[0].shape == index.shape and torch.equal(hit[0], index):
+        return hit[1]
+    n = window * window
+    dev = index.device
+    dense = torch.full((64, 64), -2, dtype=torch.long, device=dev)  # [query][key] -> table row
+    dense[:, n:] = -1
+    dense[:n, :n] = index.reshape(n, n).long()
+    lane = torch.arange(64, device=dev)
+    if order == '32':  # [qt 2][kt 2][lane 64][16]: query 32*qt + (l & 31), key 32*kt + (r & 3) + 8*(r >> 2) + 4*(l >> 5)
+        r = torch.arange(16, device=dev)
+        q_in = (lane & 31)[:, None].expand(64, 16)
+        k_in = ((r & 3) + 8 * (r >> 2))[None, :] + 4 * (lane >> 5)[:, None]
+        lut = torch.stack([torch.stack([dense[32 * qt + q_in, 32 * kt + k_in] for kt in range(2)]) for qt in range(2)])
+    else:  # [kt 4][qt 4][lane 64][4]: key 16*kt + 4*(l >> 4) + r, query 16*qt + (l & 15)
+        r = torch.arange(4, device=dev)
+        q_in = (lane & 15)[:, None].expand(64, 4)
+        k_in = 4 * (lane >> 4)[:, None] + r[None, :]
+        lut = torch.stack([torch.stack([dense[16 * qt + q_in, 16 * kt + k_in] for qt in range(4)]) for kt in range(4)])
+    _FRAG_LUT[key] = (index.clone(), lut)
+    return lut
+
+
+def _gather_fragments(table: torch.Tensor, lut: torch.Tensor, scale: float) -> torch.Tensor:
+    t = table.to(torch.float32)
+    if scale != 1.0:
+        t = t * scale
+    g = t[lut.clamp(min=0).reshape(-1)].reshape(*lut.shape, t.shape[1])  # [..., heads]
+    pad = torch.where(lut == -1, -1e30, 0.0).to(torch.float32)[..., None]
+    return torch.where((lut >= 0)[..., None], g, pad).movedim(-1, 0).contiguous()
+
+
 def bias_fragments(table: torch.Tensor, index: torch.Tensor, window: int) -> torch.Tensor:
     """table[(2w-1)^2, heads] gathered by index[w^2, w^2] -> [heads][qt 2][kt 2][lane 64][16] f32 in the S^T accumulator order:
     lane l, element r  <->  query 32*qt + (l & 31),  key 32*kt + (r & 3) + 8*(r >> 2) + 4*(l >> 5).  Padded keys get -1e30."""
-    n = window * window
-    heads = table.shape[1]
-    dense = torch.zeros((heads, 64, 64), dtype=torch.float32, device=table.device)
-    dense[:, :, n:] = -1e30
-    dense[:, :n, :n] = table.to(torch.float32)[index.reshape(-1).long()].reshape(n, n, heads).permute(2, 0, 1)
-    lane = torch.arange(64, device=table.device)
-    r = torch.arange(16, device=table.device)
-    q_in = (lane & 31)[:, None].expand(64, 16)
-    k_in = ((r & 3) + 8 * (r >> 2))[None, :] + 4 * (lane >> 5)[:, None]
-    out = torch.empty((heads, 2, 2, 64, 16), dtype=torch.float32, device=table.device)
-    for qt in range(2):
-        for kt in range(2):
-            out[:, qt, kt] = dense[:, 32 * qt + q_in, 32 * kt + k_in]
-    return out.contiguous()
+    return _gather_fragments(table, _fragment_lut(index, window, '32'), 1.0)
 
 
 def bias_fragments16(table: torch.Tensor, index: torch.Tensor, window: int) -> torch.Tensor:
     """The same gather in the accumulator order of 16x16 tiles (csrc/swin_block.hip): [heads][kt 4][qt 4][lane 64][4] f32,
     lane l, element r  <->  key 16*kt + 4*(l >> 4) + r,  query 16*qt + (l & 15).  Values are multiplied by log2(e): the kernel's
     softmax runs in base 2 (one v_exp_f32 per logit).  Padded keys get -1e30."""
-    n = window * window
-    heads = table.shape[1]
-    dense = torch.zeros((heads, 64, 64), dtype=torch.float32, device=table.device)  # [head][query][key]
-    dense[:, :, n:] = -1e30
-    dense[:, :n, :n] = table.to(torch.float32)[index.reshape(-1).long()].reshape(n, n, heads).permute(2, 0, 1) * math.log2(math.e)
-    lane = torch.arange(64, device=table.device)
-    r = torch.arange(4, device=table.device)
-    q_in = (lane & 15)[:, None].expand(64, 4)
-    k_in = 4 * (lane >> 4)[:, None] + r[None, :]
-    out = torch.empty((heads, 4, 4, 64, 4), dtype=torch.float32, device=table.device)
-    for kt in range(4):
-        for qt in range(4):
-            out[:, kt, qt] = dense[:, 16 * qt + q_in, 16 * kt + k_in]
-    return out.contiguous()
+    return _gather_fragments(table, _fragment_lut(index, window, '16'), math.log2(math.e))
 
 
 def regroup_qkv(w: torch.Tensor, b: torch.Tensor | None, heads: int, scale_q: bool = True) -> tuple[torch.Tensor, torch.Tensor]:

@@ -728,24 +728,61 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const rsa_dwconv_params p) 
       bet[j] = p.beta[pl * 8 + j];
     }
   }
+  // One ROW of taps at a time, every load of the row issued before its first use: out-of-map taps read a clamped (valid) address and are
+  // multiplied by 0 (zero padding applies to the normalised input).  The first form tested the bounds around each tap: a divergent block
+  // with its own wait per tap -- nine dependent round trips (253 us for 23 planes at 512^2; profiles/r04_v_dat_stream_kernels.txt).
+  const bool has_lo = in_lo != nullptr;  // uniform
 #pragma unroll
-  for (int dy = -R; dy <= R; ++dy)
+  for (int dy = -R; dy <= R; ++dy) {
+    bf16x8 rh[KS], rl[KS];
+    float mean[KS], rstd[KS], inside[KS];
+    const int yy = min(max(y + dy, 0), p.H - 1);
+    const bool yok = (unsigned)(y + dy) < (unsigned)p.H;
 #pragma unroll
-    for (int dx = -R; dx <= R; ++dx) {
-      const int yy = y + dy, xx = x + dx;
-      if (yy < 0 || yy >= p.H || xx < 0 || xx >= p.W) continue;
+    for (int t = 0; t < KS; ++t) {
+      const int xx = min(max(x + t - R, 0), p.W - 1);
       const int64_t q = (int64_t)yy * p.W + xx;
-      float v[8];
-      unit_f32(in_hi, in_lo, q, v, p.fmt);
+      rh[t] = in_hi[q];
+      if (has_lo) rl[t] = in_lo[q];
       if (NORM) {
-        const float mean = p.stats[((int64_t)n * HW + q) * 2], rstd = p.stats[((int64_t)n * HW + q) * 2 + 1];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (v[j] - mean) * rstd * gam[j] + bet[j];
+        const float2 st = *(const float2*)&p.stats[((int64_t)n * HW + q) * 2];
+        mean[t] = st.x, rstd[t] = st.y;
       }
-      const int tap = (dy + R) * KS + dx + R;
+      inside[t] = (yok && (unsigned)(x + t - R) < (unsigned)p.W) ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+      float v[8];
+      if (p.fmt == RSA_PF_F16) {
+        const f16x8_t hf = __builtin_bit_cast(f16x8_t, rh[t]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)hf[j];
+        if (has_lo) {
+          const f16x8_t lf = __builtin_bit_cast(f16x8_t, rl[t]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += (float)lf[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)rh[t][j];
+        if (has_lo) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += (float)rl[t][j];
+        }
+      }
+      if (NORM) {
+        const float a = rstd[t] * inside[t], b = -mean[t] * a;  // (v - mean) * rstd * gamma + beta, zero outside the map
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (v[j] * a + b) * gam[j] + bet[j] * inside[t];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= inside[t];
+      }
+      const int tap = (dy + R) * KS + t;
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] += wt[j * KK + tap] * v[j];
     }
+  }
   if (GELU) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = gelu_erf(acc[j]);

@@ -31,18 +31,19 @@ def fold_conv3xc(sd: dict, prefix: str) -> tuple[torch.Tensor, torch.Tensor]:
     The first 1x1 sees a zero-padded input, so its bias b1 reaches every tap, border pixels included --
     which is what the reference's ``conv(pad0(x))`` does as well (spanplus/arch.py:95-97).
     """
-    d = torch.float64
-    w1 = sd[f'{prefix}.conv.0.weight'].to(d)[:, :, 0, 0]
-    b1 = sd[f'{prefix}.conv.0.bias'].to(d)
-    w2 = sd[f'{prefix}.conv.1.weight'].to(d)
-    b2 = sd[f'{prefix}.conv.1.bias'].to(d)
-    w3 = sd[f'{prefix}.conv.2.weight'].to(d)[:, :, 0, 0]
-    b3 = sd[f'{prefix}.conv.2.bias'].to(d)
+    dev = sd[f'{prefix}.conv.1.weight'].device
+
+    def get(k):  # on the host: the tensors are a few hundred KB, and the first f64 contraction on the GPU costs 0.2 s of library start-up
+        return sd[f'{prefix}.{k}'].detach().to('cpu', torch.float64)
+
+    w1, b1 = get('conv.0.weight')[:, :, 0, 0], get('conv.0.bias')
+    w2, b2 = get('conv.1.weight'), get('conv.1.bias')
+    w3, b3 = get('conv.2.weight')[:, :, 0, 0], get('conv.2.bias')
     w = torch.einsum('on,nmyx,mi->oiyx', w3, w2, w1)
     b = w3 @ (torch.einsum('nmyx,m->n', w2, b1) + b2) + b3
-    w[:, :, 1, 1] += sd[f'{prefix}.sk.weight'].to(d)[:, :, 0, 0]
-    b = b + sd[f'{prefix}.sk.bias'].to(d)
-    return w.to(torch.float32), b.to(torch.float32)
+    w[:, :, 1, 1] += get('sk.weight')[:, :, 0, 0]
+    b = b + get('sk.bias')
+    return w.to(torch.float32).to(dev), b.to(torch.float32).to(dev)
 
 
 def conv3xc_shapes(shapes: dict, name: str, cout: int, cin: int, gain: int = 2) -> None:
