@@ -51,7 +51,7 @@ inline bool conv_ring_xres_eligible(const rsa_conv_params& p) {
          p.out_fmt == RSA_PF_F16 && p.res_fmt == RSA_PF_F16 && p.res1_hi != nullptr && p.res1_lo != nullptr && p.res1_hi == p.in_hi &&
          p.res_plane_stride == p.in_plane_stride && p.res_batch_stride == p.in_batch_stride && (p.res2_hi == nullptr || p.res2_lo != nullptr) &&
          (p.act == RSA_ACT_NONE || (p.act == RSA_ACT_LRELU && p.act_param >= 0.f && p.act_param <= 1.f)) &&
-         (p.lo8_flags == 0 || p.lo8_flags == (RSA_LO8_RES1 | RSA_LO8_OUT | (p.res2_hi != nullptr ? RSA_LO8_RES2 : 0)));  // lo halves all fp16 or all 8-bit
+         (p.lo8_flags == 0 || (p.lo8_flags | RSA_LO8_OUT) == (RSA_LO8_RES1 | RSA_LO8_OUT | (p.res2_hi != nullptr ? RSA_LO8_RES2 : 0)));  // lo halves all fp16, all 8-bit, or 8-bit residuals with an fp16 lo output (the last block of a trunk)
 }
 // The growth convolutions of a dense block in the one-product fp16 mode: hi-only fp16 plane output, LeakyReLU (slope in [0, 1]) or no
 // activation, whole cout tiles, no residual, no f32 map (conv_ring.h, XRES 2: the epilogue shape EM 1 called directly).

@@ -253,7 +253,8 @@ struct GeoLW {
 // they are read from there (slot geometry: units per slot / per plane / per halo row) instead of a second time from memory; lo halves come
 // from res1_lo as before.
 // L8: the lo halves of the plane residuals / outputs as 8-bit codes (rsa_conv_params.lo8_flags): -1 = as the descriptor's flags say (the generic
-// body), 0 = none, 1 = every lo operand of the launch (the direct instantiation of conv5 inside an RRDBNet trunk: no runtime tests, no spills)
+// body), 0 = none, 1 = every lo operand of the launch (the direct instantiation of conv5 inside an RRDBNet trunk: no runtime tests, no spills),
+// 2 = the residuals only (the trunk's last block hands fp16 lo halves to the three-product layers behind it)
 template <int NCT, int CTW, int NPT, int OUTK, int AC, int EM = 0, int PF = 0, int XL = 0, int L8 = -1>
 __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f32x4 (&acc)[NPT][CTW], int n, int y0, int x0, int slab, int wct,
                                               int wpx, int li, int lg, const uint4* x_lds = nullptr, uint32_t xslots = 0u, int x_slot = 0,
@@ -273,8 +274,8 @@ __device__ __forceinline__ void epilogue_impl(const rsa_conv_params& p, const f3
   const bool OF16 = G ? p.out_fmt == RSA_PF_F16 : PF == RSA_PF_F16;  // plane format of the outputs / of the plane residuals
   const bool RF16 = G ? p.res_fmt == RSA_PF_F16 : PF == RSA_PF_F16;
   // lo halves as 8-bit codes (fp16 planes only; wave-uniform)
-  const bool R1L8 = L8 < 0 ? (G && (p.lo8_flags & RSA_LO8_RES1) != 0) : L8 == 1, R2L8 = L8 < 0 ? (G && (p.lo8_flags & RSA_LO8_RES2) != 0) : L8 == 1,
-             OL8 = L8 < 0 ? (G && (p.lo8_flags & RSA_LO8_OUT) != 0) : L8 == 1;
+  const bool R1L8 = L8 < 0 ? (G && (p.lo8_flags & RSA_LO8_RES1) != 0) : L8 >= 1, R2L8 = L8 < 0 ? (G && (p.lo8_flags & RSA_LO8_RES2) != 0) : L8 >= 1,
+             OL8 = L8 < 0 ? (G && (p.lo8_flags & RSA_LO8_OUT) != 0) : L8 == 1;  // (L8 2: the residuals only)
   const bool PRELU = G && p.act == RSA_ACT_PRELU;
   const float lin_slope = p.act == RSA_ACT_NONE ? 1.f : p.act_param;  // EM 1 / 2: act(v) = max(v, v * slope)
 #ifdef RSA_ABL_NOEPI

@@ -4,8 +4,10 @@
 
 namespace rsa {
 int conv_launch_ring1_f16(const rsa_conv_params& p, hipStream_t stream) {
-  if (p.products == 1 && conv_ring_xres_enabled() && conv_ring_xres_eligible(p))
-    return p.lo8_flags ? launch_ring<1, 0, 0, 0, RSA_PF_F16, 1, 4>(p, stream) : launch_ring<1, 0, 0, 0, RSA_PF_F16, 1, 1>(p, stream);
+  if (p.products == 1 && conv_ring_xres_enabled() && conv_ring_xres_eligible(p)) {
+    if (p.lo8_flags == 0) return launch_ring<1, 0, 0, 0, RSA_PF_F16, 1, 1>(p, stream);
+    return (p.lo8_flags & RSA_LO8_OUT) ? launch_ring<1, 0, 0, 0, RSA_PF_F16, 1, 4>(p, stream) : launch_ring<1, 0, 0, 0, RSA_PF_F16, 1, 5>(p, stream);
+  }
   return p.products == 1 ? launch_ring<1, 0, 0, 0, RSA_PF_F16, 1>(p, stream) : launch_ring<1, 0, 0, 0, RSA_PF_F16, 3>(p, stream);
 }
 unsigned int conv_ring1h_aborts() { return ring_aborts_this_unit(); }

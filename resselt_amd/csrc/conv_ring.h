@@ -162,11 +162,12 @@ __device__ __forceinline__ void dma16_v(uint32_t lds_addr, gcptr vaddr) {
 // linear) with its shape folded (conv_common.h, EM 4) instead of going through the generic dispatch (141 spilled scalar registers, 64 B of scratch).
 template <int SHAPE, int UP, int OUTK, int HM = 0, int FMT = 0, int PROD = 3, int XRES = 0, int XAC = 0>
 __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(const rsa_conv_params p, const RingAux aux) {
-  static_assert((XRES != 1 && XRES != 4) || (SHAPE == 1 && PROD == 1 && HM == 0 && UP == 0 && OUTK == 0), "XRES 1 / 4: conv5 of a residual dense block only");
+  static_assert((XRES != 1 && XRES != 4 && XRES != 5) || (SHAPE == 1 && PROD == 1 && HM == 0 && UP == 0 && OUTK == 0), "XRES 1 / 4 / 5: conv5 of a residual dense block only");
   static_assert(XRES != 2 || (PROD == 1 && FMT == RSA_PF_F16 && OUTK == 0), "XRES 2: one fp16 product, hi-only plane output");
   static_assert(XRES != 3 || (SHAPE == 3 && PROD == 1 && FMT == RSA_PF_F16 && HM == 1 && UP == 0 && OUTK == 0), "XRES 3: the 48-channel SPAN-family layers");
   constexpr bool WL = XRES == 3;
-  constexpr bool XR = XRES == 1 || XRES == 4;  // XRES 4 = XRES 1 with every lo operand (residuals, output) as 8-bit codes (rsa_conv_params.lo8_flags)
+  constexpr bool XR = XRES == 1 || XRES == 4 || XRES == 5;  // XRES 4 = XRES 1 with every lo operand (residuals, output) as 8-bit codes (rsa_conv_params.lo8_flags);
+                                                            // XRES 5: the residuals' lo halves as codes, the output's as fp16 (the last block of a trunk)
                                               // (XRES 2: the growth convolutions of a dense block -- hi-only fp16 plane output, LeakyReLU / none, nothing else:
                                   //  the kernel calls that one epilogue shape directly; without the generic dispatch and its dozen descriptor
                                   //  tests it keeps 40 fewer lane registers and 140 fewer scalar registers in scratch)
@@ -527,9 +528,9 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
       } else if (XR) {
         if (!RING_DBG(8)) {
           if (p.res2_hi != nullptr)
-            epilogue_impl<NCT, CTW, NPT, 0, AC_LINEAR, 3, RSA_PF_F16, 1, XRES == 4 ? 1 : 0>(p, acc, n, ty * TH, tx * TW, 0, wct, wpx, li, lg, s_ring, xslots, SLOT, PS, IW);
+            epilogue_impl<NCT, CTW, NPT, 0, AC_LINEAR, 3, RSA_PF_F16, 1, XRES == 4 ? 1 : (XRES == 5 ? 2 : 0)>(p, acc, n, ty * TH, tx * TW, 0, wct, wpx, li, lg, s_ring, xslots, SLOT, PS, IW);
           else
-            epilogue_impl<NCT, CTW, NPT, 0, AC_LINEAR, 2, RSA_PF_F16, 1, XRES == 4 ? 1 : 0>(p, acc, n, ty * TH, tx * TW, 0, wct, wpx, li, lg, s_ring, xslots, SLOT, PS, IW);
+            epilogue_impl<NCT, CTW, NPT, 0, AC_LINEAR, 2, RSA_PF_F16, 1, XRES == 4 ? 1 : (XRES == 5 ? 2 : 0)>(p, acc, n, ty * TH, tx * TW, 0, wct, wpx, li, lg, s_ring, xslots, SLOT, PS, IW);
         }
         // the residual's LDS reads have been consumed (their values are in the stores above): hand x's four slots back
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
