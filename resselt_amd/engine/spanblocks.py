@@ -144,8 +144,10 @@ def pack_span_family(module, device, products: int, conv3xc_names: list[str], pl
         w, b = fold_conv3xc(sd, name)
         prod, fmt = span_layer_policy(name, True) if mixed else (int(products), getattr(products, 'fmt', None))
         # the first convolution (3 input channels) is packed over a whole 16-channel half chunk: its input planes carry a second, all-zero plane
-        # so that the layer takes the ring schedule (archs/spanplus/arch.py::_build_plan)
-        W[name] = ops.ConvWeights.from_oihw(w, b, prod, device=device, fmt=fmt, cin_planes=2 if name in SPAN_FIRST and w.shape[1] <= 8 else None)
+        # so that the layer takes the ring schedule (archs/spanplus/arch.py::_build_plan) -- only where the ring takes the padded layer at all:
+        # three products and three cout tiles (33..48 features); elsewhere the extra plane would only be extra work for the chunk-barrier kernel
+        ring_first = name in SPAN_FIRST and w.shape[1] <= 8 and int(prod) == 3 and (w.shape[0] + 15) // 16 == 3
+        W[name] = ops.ConvWeights.from_oihw(w, b, prod, device=device, fmt=fmt, cin_planes=2 if ring_first else None)
     for name in plain_names:
         prod, fmt = span_layer_policy(name, False) if mixed else (int(products), getattr(products, 'fmt', None))
         W[name] = ops.ConvWeights.from_oihw(sd[f'{name}.weight'], sd.get(f'{name}.bias'), prod, device=device, fmt=fmt)
