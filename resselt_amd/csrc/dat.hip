@@ -50,6 +50,18 @@ __device__ __forceinline__ void unit_f32(const bf16x8* hi, const bf16x8* lo, int
   }
 }
 
+// a raw 16-byte unit already in registers -> f32 (the loads issued earlier, several at a time)
+__device__ __forceinline__ void raw_f32(const bf16x8 h, const bf16x8 l, bool has_lo, float (&v)[8], int fmt) {
+  if (fmt == RSA_PF_F16) {
+    const f16x8_t hf = __builtin_bit_cast(f16x8_t, h), lf = __builtin_bit_cast(f16x8_t, l);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = has_lo ? (float)hf[j] + (float)lf[j] : (float)hf[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = has_lo ? (float)h[j] + (float)l[j] : (float)h[j];
+  }
+}
+
 __device__ __forceinline__ void store_unit(bf16x8* hi, bf16x8* lo, int64_t u, const float (&v)[8], int fmt = RSA_PF_BF16) {
   if (fmt == RSA_PF_F16) {
     f16x8_t h, l;
@@ -599,7 +611,8 @@ __global__ __launch_bounds__(512, 1) void rect_attention_wide_kernel(const rsa_r
 }
 
 // ------------------------------------------------------------------------------------------------ channel attention weights
-constexpr int CA_TOK = 2048;                 // tokens per partial Gram matrix
+constexpr int CA_TOK = 512;                  // tokens per partial Gram matrix (round 4: 2048 -> 512; at 512^2 x 6 heads the grid was 768 single-wave
+                                             // workgroups, less than one wave per SIMD, each with eight waited-for loads per 64 tokens: 240 us)
 constexpr int CA_REC = 32 * 32 + 64;         // floats per partial: G[32][32], |q|^2[32], |k|^2[32]
 
 // grid (chunks, heads, batch), one wave: partial G = sum_tokens q^T k over CA_TOK tokens, f32 FMA on hi+lo reconstructions.
@@ -622,20 +635,26 @@ __global__ __launch_bounds__(64) void channel_gram_kernel(const rsa_channel_attn
   for (int it = 0; it < CA_TOK / 64; ++it) {
     const int64_t tok = t0 + it * 64 + lane;
     __syncthreads();
+    // all eight units of the token first (tokens past the end re-read the last one and are zeroed), then the conversions
+    const int64_t tokc = tok < HW ? tok : HW - 1;
+    const float keep = tok < HW ? 1.f : 0.f;
+    bf16x8 rqh[4], rkh[4], rql[4], rkl[4];
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl) {
+      rqh[pl] = q_hi[pl * p.plane_stride + tokc];
+      rkh[pl] = k_hi[pl * p.plane_stride + tokc];
+      rql[pl] = q_lo != nullptr ? q_lo[pl * p.plane_stride + tokc] : rqh[pl];
+      rkl[pl] = k_lo != nullptr ? k_lo[pl * p.plane_stride + tokc] : rkh[pl];
+    }
 #pragma unroll
     for (int pl = 0; pl < 4; ++pl) {
       float qv[8], kv[8];
-      if (tok < HW) {
-        unit_f32(q_hi, q_lo, pl * p.plane_stride + tok, qv, p.fmt);
-        unit_f32(k_hi, k_lo, pl * p.plane_stride + tok, kv, p.fmt);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) qv[j] = kv[j] = 0.f;
-      }
+      raw_f32(rqh[pl], rql[pl], q_lo != nullptr, qv, p.fmt);
+      raw_f32(rkh[pl], rkl[pl], k_lo != nullptr, kv, p.fmt);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        s_q[lane][pl * 8 + j] = qv[j];
-        s_k[lane][pl * 8 + j] = kv[j];
+        s_q[lane][pl * 8 + j] = qv[j] * keep;
+        s_k[lane][pl * 8 + j] = kv[j] * keep;
       }
     }
     __syncthreads();
@@ -667,7 +686,8 @@ __global__ __launch_bounds__(1024) void channel_attn_finish_kernel(const rsa_cha
   const int head = blockIdx.x, n = blockIdx.y;
   const float* rec = p.workspace + ((int64_t)n * p.heads + head) * chunks * CA_REC;
   float g = 0.f, nq = 0.f, nk = 0.f;
-  for (int c = 0; c < chunks; ++c) {
+#pragma unroll 16
+  for (int c = 0; c < chunks; ++c) {  // fixed order: the result does not depend on the schedule
     g += rec[(int64_t)c * CA_REC + i * 32 + j];
     nq += rec[(int64_t)c * CA_REC + 1024 + i];
     nk += rec[(int64_t)c * CA_REC + 1056 + j];
@@ -705,15 +725,20 @@ __global__ __launch_bounds__(1024) void channel_attn_finish_kernel(const rsa_cha
 }
 
 // ------------------------------------------------------------------------------------------------ depthwise 3x3
-// thread = (pixel, plane of 8 channels); grid (ceil(HW/256), planes, batch)
+// thread = (pixel, plane of 8 channels); grid (tiles of DW_TW x DW_TH pixels, planes, batch).  Round 4: a workgroup is a 32 x 8 pixel TILE, not
+// 256 consecutive pixels of a row: the three rows a row-shaped workgroup reads were fetched by three workgroups on three XCDs (consecutive
+// workgroups go round-robin over the XCDs), i.e. three times from beyond the L2s; a tile reads a 34 x 10 halo region once (1.33 x).
+constexpr int DW_TW = 32, DW_TH = 8;
 template <bool NORM, bool GELU, int KS>
 __global__ __launch_bounds__(256) void dwconv_kernel(const rsa_dwconv_params p) {
   constexpr int R = KS / 2, KK = KS * KS;
   const int64_t HW = (int64_t)p.H * p.W;
-  const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int tiles_x = (p.W + DW_TW - 1) / DW_TW;
+  const int ty = (int)blockIdx.x / tiles_x, tx = (int)blockIdx.x - ty * tiles_x;
+  const int x = tx * DW_TW + (int)(threadIdx.x & (DW_TW - 1)), y = ty * DW_TH + (int)(threadIdx.x / DW_TW);
   const int pl = blockIdx.y, n = blockIdx.z;
-  if (pix >= HW) return;
-  const int y = (int)(pix / p.W), x = (int)(pix - (int64_t)y * p.W);
+  if (x >= p.W || y >= p.H) return;
+  const int64_t pix = (int64_t)y * p.W + x;
   const bf16x8* in_hi = (const bf16x8*)p.in_hi + (int64_t)n * p.in_batch_stride + (int64_t)pl * p.in_plane_stride;
   const bf16x8* in_lo = p.in_lo ? (const bf16x8*)p.in_lo + (int64_t)n * p.in_batch_stride + (int64_t)pl * p.in_plane_stride : nullptr;
   const float* wt = p.weight + pl * 8 * KK;
@@ -809,28 +834,27 @@ __global__ __launch_bounds__(256) void plane_stats_kernel(const bf16x8* in_hi, c
   const bf16x8* hi = in_hi + (int64_t)n * batch_stride;
   const bf16x8* lo = in_lo ? in_lo + (int64_t)n * batch_stride : nullptr;
   const int planes = (C + 7) / 8;
-  float sum = 0.f;
+  // ONE pass (round 4): sums of (x - s) and (x - s)^2 with s = the token's first channel, so that nothing is read twice -- the second pass of
+  // the two-pass form came from beyond the L2 again (12 MB of resident working set per XCD) -- and the variance does not cancel:
+  // var = E[(x - s)^2] - (E[x - s])^2 with |mean - s| of the order of the standard deviation.
+  float s0 = 0.f, a = 0.f, b = 0.f;
   for (int pl = 0; pl < planes; ++pl) {
     float v[8];
     unit_f32(hi, lo, pl * plane_stride + pix, v, fmt);
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (pl * 8 + j < C) sum += v[j];
-  }
-  const float mean = sum / (float)C;
-  float var = 0.f;
-  for (int pl = 0; pl < planes; ++pl) {
-    float v[8];
-    unit_f32(hi, lo, pl * plane_stride + pix, v, fmt);
+    if (pl == 0) s0 = v[0];
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       if (pl * 8 + j < C) {
-        const float d = v[j] - mean;
-        var += d * d;
+        const float d = v[j] - s0;
+        a += d;
+        b += d * d;
       }
   }
+  const float ma = a / (float)C;
+  const float mean = s0 + ma;
+  const float var = fmaxf(b / (float)C - ma * ma, 0.f);
   stats[((int64_t)n * HW + pix) * 2] = mean;
-  stats[((int64_t)n * HW + pix) * 2 + 1] = 1.f / sqrtf(var / (float)C + eps);
+  stats[((int64_t)n * HW + pix) * 2 + 1] = 1.f / sqrtf(var + eps);
 }
 
 // ------------------------------------------------------------------------------------------------ channel gate
@@ -1078,7 +1102,9 @@ extern "C" int rsa_dwconv3x3(const rsa_dwconv_params* p, void* stream) {
   if (misaligned(p->in_hi) || misaligned(p->in_lo) || misaligned(p->mul_hi) || misaligned(p->mul_lo) || misaligned(p->out_hi) || misaligned(p->out_lo))
     return set_error(RSA_E_ALIGN, "dwconv3x3: maps must be 16-byte aligned");
   const int64_t HW = (int64_t)p->H * p->W;
-  const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)p->planes, (unsigned)p->batch), block(256);
+  const int64_t tiles = (int64_t)((p->W + DW_TW - 1) / DW_TW) * ((p->H + DW_TH - 1) / DW_TH);
+  if (tiles > 0x7fffffff) return set_error(RSA_E_UNSUPPORTED, "dwconv3x3: map too large");
+  const dim3 grid((unsigned)tiles, (unsigned)p->planes, (unsigned)p->batch), block(256);
   hipStream_t s = (hipStream_t)stream;
   const bool gelu = p->act == RSA_ACT_GELU;
   if (p->stats) {
@@ -1101,8 +1127,9 @@ extern "C" int rsa_dwconv5x5(const rsa_dwconv_params* p, void* stream) {
   if (misaligned(p->in_hi) || misaligned(p->in_lo) || misaligned(p->mul_hi) || misaligned(p->mul_lo) || misaligned(p->out_hi) || misaligned(p->out_lo))
     return set_error(RSA_E_ALIGN, "dwconv5x5: maps must be 16-byte aligned");
   const int64_t HW = (int64_t)p->H * p->W;
-  hipLaunchKernelGGL((dwconv_kernel<false, false, 5>), dim3((unsigned)((HW + 255) / 256), (unsigned)p->planes, (unsigned)p->batch), dim3(256), 0,
-                     (hipStream_t)stream, *p);
+  const int64_t tiles = (int64_t)((p->W + DW_TW - 1) / DW_TW) * ((p->H + DW_TH - 1) / DW_TH);
+  if (tiles > 0x7fffffff) return set_error(RSA_E_UNSUPPORTED, "dwconv5x5: map too large");
+  hipLaunchKernelGGL((dwconv_kernel<false, false, 5>), dim3((unsigned)tiles, (unsigned)p->planes, (unsigned)p->batch), dim3(256), 0, (hipStream_t)stream, *p);
   const hipError_t rc = hipGetLastError();
   return rc ? set_error(rc, "dwconv5x5: launch failed") : RSA_OK;
 }
