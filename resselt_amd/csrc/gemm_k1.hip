@@ -19,12 +19,16 @@ namespace rsa {
 __device__ uint4 g_zero_unit_gk[4];  // source of zero units for lanes past the end of the token map (never written)
 
 constexpr int GK_WAVES = 8;
+#ifndef GK_MINW
+#define GK_MINW(PROD, NQ) (((PROD) == 1 && (NQ) == 6) ? 4 : 2)  // waves per SIMD the registers must allow (NQ 6: see gemm_k1_launch).  The 64 KB one-product form takes 157 VGPRs = ONE workgroup per CU; forcing 128
+                             // (4: two workgroups per CU, 26 spills) is 6-9 % slower on DAT / HAT / DRCT (profiles/r04_zz_gemm_k1_occupancy_ab.txt)
+#endif
 
 // TP = pixels per tile (64, or 32 when the whole-K image of 64 pixels would not fit twice in LDS)
 // FMT: plane format of the input planes and weights (selects the matrix instruction); the outputs follow p.out_fmt.  Round 3: one fp16
 // product on hi planes (PROD 1, FMT RSA_PF_F16) -- the Linear layers of DRCT / HAT / DAT under their 'mixed' precision policies.
 template <int PROD, int CTW, int NQ, int GK_TP, int FMT = 0>
-__global__ __launch_bounds__(GK_WAVES * 64, 2) void gemm_k1_kernel(const rsa_conv_params p) {
+__global__ __launch_bounds__(GK_WAVES * 64, GK_MINW(PROD, NQ)) void gemm_k1_kernel(const rsa_conv_params p) {
   constexpr int NHL = (PROD == 3) ? 2 : 1;
   constexpr int NPT = GK_TP / 16;
   // LDS image of one tile: [hi|lo][K-chunk q][plane in chunk 4][64 pixels] units; two buffers
@@ -300,6 +304,9 @@ int gemm_k1_launch(const rsa_conv_params& p, hipStream_t stream) {
   } else {
     // one product: a K of at most 256 channels takes the 8-chunk image (2 x 32 KB of LDS: two workgroups per CU, which the register budget of
     // the kernel already allows; the 16-chunk image fills the LDS with one)
+    // K <= 192 on fp16 planes (the 180-channel bodies of DAT / HAT / DRCT): six chunks of weights are 48 registers instead of 64, which brings
+    // the kernel under 128 VGPRs without spills = TWO workgroups per CU (round 4)
+    if (nq <= 6 && p.in_fmt == RSA_PF_F16) return launch_gemm<1, 2, 6, 64, RSA_PF_F16>(p, stream);
     if (nq <= 8) return p.in_fmt == RSA_PF_F16 ? launch_gemm<1, 2, 8, 64, RSA_PF_F16>(p, stream) : launch_gemm<1, 2, 8, 64>(p, stream);
     if (nq <= 16) return p.in_fmt == RSA_PF_F16 ? launch_gemm<1, 2, 16, 64, RSA_PF_F16>(p, stream) : launch_gemm<1, 2, 16, 64>(p, stream);
   }
