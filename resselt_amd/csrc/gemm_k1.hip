@@ -19,6 +19,9 @@ namespace rsa {
 __device__ uint4 g_zero_unit_gk[4];  // source of zero units for lanes past the end of the token map (never written)
 
 constexpr int GK_WAVES = 8;
+#ifndef RSA_GK_ABL
+#define RSA_GK_ABL 0  // experiment builds (tools/variant.sh): 1 = tiles after the first two are not fetched, 2 = no plane / map stores, 4 = no MFMAs
+#endif
 #ifndef GK_MINW
 #define GK_MINW(PROD, NQ) (((PROD) == 1 && (NQ) == 6) ? 4 : 2)  // waves per SIMD the registers must allow (NQ 6: see gemm_k1_launch).  The 64 KB one-product form takes 157 VGPRs = ONE workgroup per CU; forcing 128
                              // (4: two workgroups per CU, 26 spills) is 6-9 % slower on DAT / HAT / DRCT (profiles/r04_zz_gemm_k1_occupancy_ab.txt)
@@ -27,7 +30,10 @@ constexpr int GK_WAVES = 8;
 // TP = pixels per tile (64, or 32 when the whole-K image of 64 pixels would not fit twice in LDS)
 // FMT: plane format of the input planes and weights (selects the matrix instruction); the outputs follow p.out_fmt.  Round 3: one fp16
 // product on hi planes (PROD 1, FMT RSA_PF_F16) -- the Linear layers of DRCT / HAT / DAT under their 'mixed' precision policies.
-template <int PROD, int CTW, int NQ, int GK_TP, int FMT = 0>
+// EPI (round 4): 0 = the generic epilogue (activation classes, f32 residual maps, f32 / plane outputs, PReLU, the SPAB gate: a dozen descriptor
+// tests per fragment pair); 1 / 2 = the direct form of the layers that only write fp16 hi planes -- qkv (no activation) and fc1 (GELU) of
+// the transformer bodies: bias, [GELU], fp16 convert, half exchange, one 16-byte store per lane and fragment pair.
+template <int PROD, int CTW, int NQ, int GK_TP, int FMT = 0, int EPI = 0>
 __global__ __launch_bounds__(GK_WAVES * 64, GK_MINW(PROD, NQ)) void gemm_k1_kernel(const rsa_conv_params p) {
   constexpr int NHL = (PROD == 3) ? 2 : 1;
   constexpr int NPT = GK_TP / 16;
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(GK_WAVES * 64, GK_MINW(PROD, NQ)) void gemm_k1_kern
     __syncthreads();  // vmcnt(0) for the DMA + everybody's rows landed
     for (; tile < num_tiles; tile += (int)gridDim.x, buf ^= 1) {
       const int ntile = tile + (int)gridDim.x;
-      if (!early && ntile < num_tiles) issue_tile(ntile, buf ^ 1);
+      if (!(RSA_GK_ABL & 1) && !early && ntile < num_tiles) issue_tile(ntile, buf ^ 1);
 
       f32x4 acc[NPT][CTW];
 #pragma unroll
@@ -151,14 +157,20 @@ __global__ __launch_bounds__(GK_WAVES * 64, GK_MINW(PROD, NQ)) void gemm_k1_kern
               for (int c = 0; c < CTW; ++c) acc[pt][c] = mfma16<FMT>(wr[c][q][0], bl, acc[pt][c]);
             }
 #pragma unroll
-            for (int c = 0; c < CTW; ++c) acc[pt][c] = mfma16<FMT>(wr[c][q][0], bh, acc[pt][c]);
+            for (int c = 0; c < CTW; ++c) {
+              if (RSA_GK_ABL & 4) {
+                acc[pt][c][0] += (float)bh[0] * (float)wr[c][q][0][0];  // keeps the operands live without the matrix pipe
+              } else {
+                acc[pt][c] = mfma16<FMT>(wr[c][q][0], bh, acc[pt][c]);
+              }
+            }
           }
         }
       }
 
       __syncthreads();  // next tile's rows have landed (vmcnt(0) also retires the PREVIOUS tile's stores, long done); all waves are done with this buffer
       f32x4 pre1[RES_PREFETCH ? CTW * NPT : 1], pre2[RES_PREFETCH ? CTW * NPT : 1];
-      if (RES_PREFETCH) {
+      if (RES_PREFETCH && EPI == 0) {
         const int n = tile / tiles_img;
         const int64_t pix0 = (int64_t)(tile - n * tiles_img) * GK_TP;
 #pragma unroll
@@ -175,10 +187,52 @@ __global__ __launch_bounds__(GK_WAVES * 64, GK_MINW(PROD, NQ)) void gemm_k1_kern
             if (p.res2 != nullptr && ok) pre2[c * NPT + pt] = ((const f32x4*)p.res2)[idx];
           }
       }
-      if (early && ntile + (int)gridDim.x < num_tiles) issue_tile(ntile + (int)gridDim.x, buf);
+      if (!(RSA_GK_ABL & 1) && early && ntile + (int)gridDim.x < num_tiles) issue_tile(ntile + (int)gridDim.x, buf);
       // ---- epilogue of this tile AFTER the barrier, so that its stores are in flight under the next tile's DMA and MFMAs instead
       //      of being drained by this barrier's vmcnt(0): lane owns channels c0..c0+3 of pixel pix0 + 16*pt + li ----
-      {
+      if constexpr (EPI != 0) {
+        const int n = tile / tiles_img;
+        const int64_t pix0 = (int64_t)(tile - n * tiles_img) * GK_TP;
+        const bool tail_tile = pix0 + GK_TP > HW;  // uniform: only the last tile of an image tests its pixels
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) {
+          const int cbase = ctg[c] * 16;  // uniform
+          if (ctg[c] >= ct_total || cbase >= cout8) continue;
+          const int c0 = cbase + lg * 4;
+          const f32x4 bias = biasv[c];
+          const bool partial = cbase + 16 > p.cout;  // uniform: the last cout tile zeroes the channels beyond Cout
+          char* ob = (char*)p.out_hi + ((int64_t)n * p.out_batch_stride + (int64_t)(p.out_plane_off + (cbase >> 3)) * p.out_plane_stride + pix0) * 16;
+          const uint32_t lane_off = ((uint32_t)(lg >> 1) * (uint32_t)p.out_plane_stride + (uint32_t)li) * 16u;
+#pragma unroll
+          for (int pp = 0; pp < NPT / 2; ++pp) {
+            uint32_t h[2][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              float v[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                v[r] = acc[pp * 2 + e][c][r] + bias[r];
+                if (EPI == 2) v[r] = act_apply<AC_GELU>(v[r], RSA_ACT_GELU, 0.f);
+              }
+              if (partial) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  if (c0 + r >= p.cout) v[r] = 0.f;
+              }
+              uint32_t lo_unused;
+              split2<RSA_PF_F16>(v[0], v[1], h[e][0], lo_unused);
+              split2<RSA_PF_F16>(v[2], v[3], h[e][1], lo_unused);
+            }
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            const u32x2 h0 = __builtin_amdgcn_permlane16_swap(h[0][0], h[1][0], false, false);
+            const u32x2 h1 = __builtin_amdgcn_permlane16_swap(h[0][1], h[1][1], false, false);
+            const int pt = pp * 2 + (lg & 1);  // the pixel tile whose whole unit this lane stores
+            if (c0 < cout8 && (!tail_tile || pix0 + pt * 16 + li < HW) && (!(RSA_GK_ABL & 2) || h0.x == 0x12345678u))
+              *(uint4*)(ob + lane_off + (uint32_t)(pt * 16) * 16u) = make_uint4(h0.x, h1.x, h0.y, h1.y);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
         const int n = tile / tiles_img;
         const int64_t pix0 = (int64_t)(tile - n * tiles_img) * GK_TP;
 #pragma unroll
@@ -252,7 +306,7 @@ __global__ __launch_bounds__(GK_WAVES * 64, GK_MINW(PROD, NQ)) void gemm_k1_kern
               const int odd = lg & 1;
               const int64_t pixs = odd ? pixe[1] : pixe[0];  // the pixel whose whole unit this lane stores (same column li in both tiles)
               const int64_t off = (outrow + pixs) * 16;
-              if (pixs < HW) {
+              if (pixs < HW && (!(RSA_GK_ABL & 2) || h0.x == 0x12345678u)) {
                 *(uint4*)((char*)p.out_hi + off) = make_uint4(h0.x, h1.x, h0.y, h1.y);
               }
               if (p.out_lo != nullptr) {
@@ -269,7 +323,7 @@ __global__ __launch_bounds__(GK_WAVES * 64, GK_MINW(PROD, NQ)) void gemm_k1_kern
   }
 }
 
-template <int PROD, int CTW, int NQ, int GK_TP, int FMT = 0>
+template <int PROD, int CTW, int NQ, int GK_TP, int FMT = 0, int EPI = 0>
 static int launch_gemm(const rsa_conv_params& p, hipStream_t stream) {
   const int64_t HW = (int64_t)p.H * p.W;
   const int64_t num_tiles = ((HW + GK_TP - 1) / GK_TP) * p.batch;
@@ -279,15 +333,23 @@ static int launch_gemm(const rsa_conv_params& p, hipStream_t stream) {
   if (resident == 0) {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_k1_kernel<PROD, CTW, NQ, GK_TP, FMT>, GK_WAVES * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_k1_kernel<PROD, CTW, NQ, GK_TP, FMT, EPI>, GK_WAVES * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipGetLastError();
     resident = per_cu * prop.multiProcessorCount;
     resident_cache.store(resident, std::memory_order_relaxed);
   }
   int gx = resident;
   if (gx > num_tiles) gx = (int)num_tiles;
-  hipLaunchKernelGGL((gemm_k1_kernel<PROD, CTW, NQ, GK_TP, FMT>), dim3((unsigned)gx), dim3(GK_WAVES * 64), 0, stream, p);
+  hipLaunchKernelGGL((gemm_k1_kernel<PROD, CTW, NQ, GK_TP, FMT, EPI>), dim3((unsigned)gx), dim3(GK_WAVES * 64), 0, stream, p);
   return (int)hipGetLastError();
+}
+
+static bool gemm_k1_direct_enabled() {  // RSA_GK_DIRECT=0 in the environment: the generic epilogue everywhere (A/B runs)
+  static const bool on = [] {
+    const char* e = getenv("RSA_GK_DIRECT");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  return on;
 }
 
 // Returns -100 when the layer is not a fit for this schedule (caller falls back to the halo-tile kernels).
@@ -306,9 +368,17 @@ int gemm_k1_launch(const rsa_conv_params& p, hipStream_t stream) {
     // the kernel already allows; the 16-chunk image fills the LDS with one)
     // K <= 192 on fp16 planes (the 180-channel bodies of DAT / HAT / DRCT): six chunks of weights are 48 registers instead of 64, which brings
     // the kernel under 128 VGPRs without spills = TWO workgroups per CU (round 4)
-    if (nq <= 6 && p.in_fmt == RSA_PF_F16) return launch_gemm<1, 2, 6, 64, RSA_PF_F16>(p, stream);
-    if (nq <= 8) return p.in_fmt == RSA_PF_F16 ? launch_gemm<1, 2, 8, 64, RSA_PF_F16>(p, stream) : launch_gemm<1, 2, 8, 64>(p, stream);
-    if (nq <= 16) return p.in_fmt == RSA_PF_F16 ? launch_gemm<1, 2, 16, 64, RSA_PF_F16>(p, stream) : launch_gemm<1, 2, 16, 64>(p, stream);
+    if (p.in_fmt == RSA_PF_F16 && nq <= 16) {
+      // the direct epilogue: fp16 hi planes out and nothing else (qkv: no activation -> EPI 1; fc1: GELU -> EPI 2)
+      const bool planes_only = gemm_k1_direct_enabled() && p.out_hi != nullptr && p.out_lo == nullptr && p.out_f32 == nullptr && p.out_fmt == RSA_PF_F16 &&
+                               p.res1 == nullptr && p.res2 == nullptr && p.out_plane_stride < (1ll << 27);
+      const int epi = !planes_only ? 0 : (p.act == RSA_ACT_NONE ? 1 : (p.act == RSA_ACT_GELU ? 2 : 0));
+      if (nq <= 6) return epi == 1 ? launch_gemm<1, 2, 6, 64, RSA_PF_F16, 1>(p, stream) : epi == 2 ? launch_gemm<1, 2, 6, 64, RSA_PF_F16, 2>(p, stream) : launch_gemm<1, 2, 6, 64, RSA_PF_F16>(p, stream);
+      if (nq <= 8) return epi == 1 ? launch_gemm<1, 2, 8, 64, RSA_PF_F16, 1>(p, stream) : epi == 2 ? launch_gemm<1, 2, 8, 64, RSA_PF_F16, 2>(p, stream) : launch_gemm<1, 2, 8, 64, RSA_PF_F16>(p, stream);
+      return epi == 1 ? launch_gemm<1, 2, 16, 64, RSA_PF_F16, 1>(p, stream) : epi == 2 ? launch_gemm<1, 2, 16, 64, RSA_PF_F16, 2>(p, stream) : launch_gemm<1, 2, 16, 64, RSA_PF_F16>(p, stream);
+    }
+    if (nq <= 8) return launch_gemm<1, 2, 8, 64>(p, stream);
+    if (nq <= 16) return launch_gemm<1, 2, 16, 64>(p, stream);
   }
   return -100;
 }
