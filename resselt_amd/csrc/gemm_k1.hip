@@ -32,7 +32,7 @@ constexpr int GK_WAVES = 8;
 // product on hi planes (PROD 1, FMT RSA_PF_F16) -- the Linear layers of DRCT / HAT / DAT under their 'mixed' precision policies.
 // EPI (round 4): 0 = the generic epilogue (activation classes, f32 residual maps, f32 / plane outputs, PReLU, the SPAB gate: a dozen descriptor
 // tests per fragment pair); 1 / 2 = the direct form of the layers that only write fp16 hi planes -- qkv (no activation) and fc1 (GELU) of
-// the transformer bodies: bias, [GELU], fp16 convert, half exchange, one 16-byte store per lane and fragment pair.
+// the transformer bodies: bias, [GELU], fp16 convert, half exchange, one 16-byte store per lane and fragment pair; 3 = the residual layers.
 template <int PROD, int CTW, int NQ, int GK_TP, int FMT = 0, int EPI = 0>
 __global__ __launch_bounds__(GK_WAVES * 64, GK_MINW(PROD, NQ)) void gemm_k1_kernel(const rsa_conv_params p) {
   constexpr int NHL = (PROD == 3) ? 2 : 1;
@@ -190,7 +190,71 @@ __global__ __launch_bounds__(GK_WAVES * 64, GK_MINW(PROD, NQ)) void gemm_k1_kern
       if (!(RSA_GK_ABL & 1) && early && ntile + (int)gridDim.x < num_tiles) issue_tile(ntile + (int)gridDim.x, buf);
       // ---- epilogue of this tile AFTER the barrier, so that its stores are in flight under the next tile's DMA and MFMAs instead
       //      of being drained by this barrier's vmcnt(0): lane owns channels c0..c0+3 of pixel pix0 + 16*pt + li ----
-      if constexpr (EPI != 0) {
+      if constexpr (EPI == 3) {
+        // the residual layers of the transformer bodies (proj, fc2, DRCT's adjust layers): no activation or LeakyReLU, an optional f32
+        // residual map (* alpha), outputs as an f32 map and / or fp16 hi planes; the descriptor's tests are wave-uniform and made once per tile
+        const int n = tile / tiles_img;
+        const int64_t pix0 = (int64_t)(tile - n * tiles_img) * GK_TP;
+        const bool tail_tile = pix0 + GK_TP > HW;
+        const bool has_res = p.res1 != nullptr, has_f32 = p.out_f32 != nullptr, has_pl = p.out_hi != nullptr;
+        const float slope = p.act == RSA_ACT_NONE ? 1.f : p.act_param;
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) {
+          const int cbase = ctg[c] * 16;  // uniform
+          if (ctg[c] >= ct_total || cbase >= cout8) continue;
+          const int c0 = cbase + lg * 4;
+          const f32x4 bias = biasv[c];
+          const bool partial = cbase + 16 > p.cout;
+          const bool grp_ok = c0 < (p4 << 2);  // this lane's channel group exists in the f32 maps
+          const int64_t frow = ((int64_t)n * p4 + (c0 >> 2)) * HW + pix0;
+          char* ob = (char*)p.out_hi + ((int64_t)n * p.out_batch_stride + (int64_t)(p.out_plane_off + (cbase >> 3)) * p.out_plane_stride + pix0) * 16;
+          const uint32_t lane_off = ((uint32_t)(lg >> 1) * (uint32_t)p.out_plane_stride + (uint32_t)li) * 16u;
+          f32x4 rr[NPT];
+#pragma unroll
+          for (int pt = 0; pt < NPT; ++pt) {
+            rr[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (has_res && grp_ok && (!tail_tile || pix0 + pt * 16 + li < HW)) rr[pt] = ((const f32x4*)p.res1)[frow + pt * 16 + li];
+          }
+#pragma unroll
+          for (int pp = 0; pp < NPT / 2; ++pp) {
+            uint32_t h[2][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int pt = pp * 2 + e;
+              float v[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = acc[pt][c][r] + bias[r];
+              if (slope != 1.f) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], v[r] * slope);
+              }
+              if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + rr[pt][r];
+              }
+              if (partial) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  if (c0 + r >= p.cout) v[r] = 0.f;
+              }
+              if (has_f32 && grp_ok && (!tail_tile || pix0 + pt * 16 + li < HW) && !(RSA_GK_ABL & 2))
+                ((f32x4*)p.out_f32)[frow + pt * 16 + li] = (f32x4){v[0], v[1], v[2], v[3]};
+              uint32_t lo_unused;
+              split2<RSA_PF_F16>(v[0], v[1], h[e][0], lo_unused);
+              split2<RSA_PF_F16>(v[2], v[3], h[e][1], lo_unused);
+            }
+            if (has_pl) {  // uniform
+              typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+              const u32x2 h0 = __builtin_amdgcn_permlane16_swap(h[0][0], h[1][0], false, false);
+              const u32x2 h1 = __builtin_amdgcn_permlane16_swap(h[0][1], h[1][1], false, false);
+              const int pt = pp * 2 + (lg & 1);
+              if (c0 < cout8 && (!tail_tile || pix0 + pt * 16 + li < HW) && !(RSA_GK_ABL & 2))
+                *(uint4*)(ob + lane_off + (uint32_t)(pt * 16) * 16u) = make_uint4(h0.x, h1.x, h0.y, h1.y);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if constexpr (EPI != 0) {
         const int n = tile / tiles_img;
         const int64_t pix0 = (int64_t)(tile - n * tiles_img) * GK_TP;
         const bool tail_tile = pix0 + GK_TP > HW;  // uniform: only the last tile of an image tests its pixels
@@ -372,10 +436,14 @@ int gemm_k1_launch(const rsa_conv_params& p, hipStream_t stream) {
       // the direct epilogue: fp16 hi planes out and nothing else (qkv: no activation -> EPI 1; fc1: GELU -> EPI 2)
       const bool planes_only = gemm_k1_direct_enabled() && p.out_hi != nullptr && p.out_lo == nullptr && p.out_f32 == nullptr && p.out_fmt == RSA_PF_F16 &&
                                p.res1 == nullptr && p.res2 == nullptr && p.out_plane_stride < (1ll << 27);
-      const int epi = !planes_only ? 0 : (p.act == RSA_ACT_NONE ? 1 : (p.act == RSA_ACT_GELU ? 2 : 0));
-      if (nq <= 6) return epi == 1 ? launch_gemm<1, 2, 6, 64, RSA_PF_F16, 1>(p, stream) : epi == 2 ? launch_gemm<1, 2, 6, 64, RSA_PF_F16, 2>(p, stream) : launch_gemm<1, 2, 6, 64, RSA_PF_F16>(p, stream);
-      if (nq <= 8) return epi == 1 ? launch_gemm<1, 2, 8, 64, RSA_PF_F16, 1>(p, stream) : epi == 2 ? launch_gemm<1, 2, 8, 64, RSA_PF_F16, 2>(p, stream) : launch_gemm<1, 2, 8, 64, RSA_PF_F16>(p, stream);
-      return epi == 1 ? launch_gemm<1, 2, 16, 64, RSA_PF_F16, 1>(p, stream) : epi == 2 ? launch_gemm<1, 2, 16, 64, RSA_PF_F16, 2>(p, stream) : launch_gemm<1, 2, 16, 64, RSA_PF_F16>(p, stream);
+      // EPI 3: no activation / LeakyReLU, an optional f32 residual, f32 map and / or fp16 hi planes out (proj, fc2, DRCT's adjust layers)
+      const bool resid = gemm_k1_direct_enabled() && p.res2 == nullptr && p.out_lo == nullptr && (p.out_hi == nullptr || p.out_fmt == RSA_PF_F16) &&
+                         (p.out_hi != nullptr || p.out_f32 != nullptr) && p.out_plane_stride < (1ll << 27) &&
+                         (p.act == RSA_ACT_NONE || (p.act == RSA_ACT_LRELU && p.act_param >= 0.f && p.act_param <= 1.f));
+      const int epi = planes_only && p.act == RSA_ACT_NONE ? 1 : (planes_only && p.act == RSA_ACT_GELU ? 2 : (resid ? 3 : 0));
+      if (nq <= 6) return epi == 1 ? launch_gemm<1, 2, 6, 64, RSA_PF_F16, 1>(p, stream) : epi == 2 ? launch_gemm<1, 2, 6, 64, RSA_PF_F16, 2>(p, stream) : epi == 3 ? launch_gemm<1, 2, 6, 64, RSA_PF_F16, 3>(p, stream) : launch_gemm<1, 2, 6, 64, RSA_PF_F16>(p, stream);
+      if (nq <= 8) return epi == 1 ? launch_gemm<1, 2, 8, 64, RSA_PF_F16, 1>(p, stream) : epi == 2 ? launch_gemm<1, 2, 8, 64, RSA_PF_F16, 2>(p, stream) : epi == 3 ? launch_gemm<1, 2, 8, 64, RSA_PF_F16, 3>(p, stream) : launch_gemm<1, 2, 8, 64, RSA_PF_F16>(p, stream);
+      return epi == 1 ? launch_gemm<1, 2, 16, 64, RSA_PF_F16, 1>(p, stream) : epi == 2 ? launch_gemm<1, 2, 16, 64, RSA_PF_F16, 2>(p, stream) : epi == 3 ? launch_gemm<1, 2, 16, 64, RSA_PF_F16, 3>(p, stream) : launch_gemm<1, 2, 16, 64, RSA_PF_F16>(p, stream);
     }
     if (nq <= 8) return launch_gemm<1, 2, 8, 64>(p, stream);
     if (nq <= 16) return launch_gemm<1, 2, 16, 64>(p, stream);
