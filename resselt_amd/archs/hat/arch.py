@@ -16,6 +16,7 @@ relative-position tables are gathered once, at pack time, into the kernel's accu
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 
 import torch
@@ -140,7 +141,7 @@ class HAT(EngineModule):
 
     @property
     def auto_precision(self) -> str:
-        return 'mixed' if self.fused_mlp and swinblocks.mlp_block_fits(self.embed_dim, int(self.embed_dim * self.mlp_ratio)) else 'bf16x3'
+        return 'mixed'
 
     @staticmethod
     def layer_policy(name: str) -> tuple[int, int]:
@@ -149,7 +150,7 @@ class HAT(EngineModule):
             return 1, PF_F16
         return 3, PF_BF16
 
-    fused_mlp = True  # LayerNorm + fc1 + GELU + fc2 + shortcut as one launch where the widths allow it (engine/swinblocks.py)
+    fused_mlp = os.environ.get('RSA_HAT_FUSED_MLP', '1') != '0'  # LayerNorm + fc1 + GELU + fc2 + shortcut as one launch where the widths allow it (engine/swinblocks.py)
 
     def __init__(self, *, img_size=64, patch_size=1, in_chans=3, embed_dim=96, depths=(6, 6, 6, 6), num_heads=(6, 6, 6, 6), window_size=7,
                  compress_ratio=3, squeeze_factor=30, conv_scale=0.01, overlap_ratio=0.5, mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
@@ -323,9 +324,7 @@ class HAT(EngineModule):
         qkv_pl = plan.planes(n, 3 * max_heads * HEAD_PAD // 8, H, Wd, **one)
         o_pl = plan.planes(n, max_heads * HEAD_PAD // 8, H, Wd, **one)
         fuse_mlp = self.fused_mlp and swinblocks.mlp_block_fits(C_, hidden)
-        if mixed and not fuse_mlp:
-            raise NotImplementedError("HAT 'mixed' needs the fused MLP half (C <= 256, hidden <= 512); use precision 'bf16x3'")
-        hid_pl = None if fuse_mlp else plan.planes(n, (hidden + 7) // 8, H, Wd, with_lo)
+        hid_pl = None if fuse_mlp else plan.planes(n, (hidden + 7) // 8, H, Wd, **one)
         body_pl = plan.planes(n, cp, H, Wd, with_lo)
         cab_a = plan.planes(n, (self.compress + 7) // 8, H, Wd, **one)
         cab_b = plan.planes(n, cp, H, Wd, with_lo)
