@@ -165,6 +165,7 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
   static_assert((XRES != 1 && XRES != 4 && XRES != 5) || (SHAPE == 1 && PROD == 1 && HM == 0 && UP == 0 && OUTK == 0), "XRES 1 / 4 / 5: conv5 of a residual dense block only");
   static_assert(XRES != 2 || (PROD == 1 && FMT == RSA_PF_F16 && OUTK == 0), "XRES 2: one fp16 product, hi-only plane output");
   static_assert(XRES != 3 || (SHAPE == 3 && PROD == 1 && FMT == RSA_PF_F16 && HM == 1 && UP == 0 && OUTK == 0), "XRES 3: the 48-channel SPAN-family layers");
+  static_assert(XRES != 6 || (SHAPE == 2 && OUTK == 1 && UP == 0), "XRES 6: final stores with at most 16 output channels");
   constexpr bool WL = XRES == 3;
   constexpr bool XR = XRES == 1 || XRES == 4 || XRES == 5;  // XRES 4 = XRES 1 with every lo operand (residuals, output) as 8-bit codes (rsa_conv_params.lo8_flags);
                                                             // XRES 5: the residuals' lo halves as codes, the output's as fp16 (the last block of a trunk)
@@ -179,6 +180,9 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
   constexpr int NCT = SHAPE == 2 ? 2 : (SHAPE == 1 ? 4 : 3);  // cout tiles of the layer handled by one workgroup
   constexpr int CTW = SHAPE == 3 ? 3 : 2;       // cout tiles per wave
   constexpr int NPT = SHAPE == 3 ? 4 : 8;       // pixel tiles per wave (RPW rows x 2 halves)
+  // XRES 6 (round 4): a final store with at most 16 output channels (the 64 -> 3 last convolution) multiplies ONE cout tile; the two-tile form
+  // issued as many MFMAs again on zero weights and was bound by them (0.92 TFLOP issued per 8.3 Mpx band in three products = its 835 us)
+  constexpr int CTU = XRES == 6 ? 1 : CTW;      // cout tiles a wave multiplies
   constexpr int RPW = NPT / 2;
   constexpr int NCONS = (STREAMS == 2) ? 4 : 8; // consumer waves per slot
   constexpr int SPS = NSLOT / STREAMS;          // slots per stream (a power of two)
@@ -344,7 +348,7 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
   bf16x8 wq[WD + 1][CTW][NHL];  // wq[0]: the K step being multiplied; wq[1..WD]: the next ones, in flight
   auto load_w = [&](int s) {    // -> wq[WD]
 #pragma unroll
-    for (int c = 0; c < CTW; ++c)
+    for (int c = 0; c < CTU; ++c)
 #pragma unroll
       for (int hl = 0; hl < NHL; ++hl) {
         if (RING_DBG(4)) continue;
@@ -360,7 +364,7 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
 #pragma unroll
     for (int d = 0; d < WD; ++d)
 #pragma unroll
-      for (int c = 0; c < CTW; ++c)
+      for (int c = 0; c < CTU; ++c)
 #pragma unroll
         for (int hl = 0; hl < NHL; ++hl) wq[d][c][hl] = wq[d + 1][c][hl];
   };
@@ -487,14 +491,14 @@ __global__ __launch_bounds__((8 + (SHAPE == 2 ? 2 : 1)) * 64, 3) void conv_ring(
 #pragma unroll
         for (int pr = 0; pr < PROD; ++pr)
 #pragma unroll
-          for (int ct = 0; ct < CTW; ++ct) {
+          for (int ct = 0; ct < CTU; ++ct) {
             // products in increasing magnitude: w_lo*a_hi, w_hi*a_lo, w_hi*a_hi
             const bf16x8 wf = (PROD == 3 && pr == 0) ? wq[0][ct][NHL - 1] : wq[0][ct][0];
             const bf16x8 bf = (PROD == 3 && pr == 1) ? rl[PROD == 3 ? i % (DEPTH + 1) : 0] : rh[i % (DEPTH + 1)];
             acc[sp][ct] = mfma16<FMT>(wf, bf, acc[sp][ct]);
           }
         if (i + DEPTH < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, NHL, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, PROD * CTW, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, PROD * CTU, 0);
         __builtin_amdgcn_sched_barrier(0);
       };
       if (HM) {
