@@ -834,25 +834,43 @@ __global__ __launch_bounds__(256) void plane_stats_kernel(const bf16x8* in_hi, c
   const bf16x8* hi = in_hi + (int64_t)n * batch_stride;
   const bf16x8* lo = in_lo ? in_lo + (int64_t)n * batch_stride : nullptr;
   const int planes = (C + 7) / 8;
-  // ONE pass (round 4): sums of (x - s) and (x - s)^2 with s = the token's first channel, so that nothing is read twice -- the second pass of
-  // the two-pass form came from beyond the L2 again (12 MB of resident working set per XCD) -- and the variance does not cancel:
-  // var = E[(x - s)^2] - (E[x - s])^2 with |mean - s| of the order of the standard deviation.
-  float s0 = 0.f, a = 0.f, b = 0.f;
+  // ONE pass (round 4): nothing is read twice -- the second pass of the two-pass form came from beyond the L2 again (12 MB of resident working
+  // set per XCD).  Each plane's 8 channels give an exact two-pass (mean, M2) in registers; the planes are combined with the pairwise update
+  // of Chan et al. (mean += d * nb / n, M2 += M2b + d^2 * na * nb / n), which has no cancellation whatever the offset of the data.
+  // Everything is done on x - s0, s0 = the mean of the first plane (an exact subtraction for data near s0), so the rounding of the running
+  // mean scales with the spread of the data, not with its offset.
+  float mean = 0.f, m2 = 0.f, s0 = 0.f;  // mean: of x - s0
+  int cnt = 0;
   for (int pl = 0; pl < planes; ++pl) {
     float v[8];
     unit_f32(hi, lo, pl * plane_stride + pix, v, fmt);
-    if (pl == 0) s0 = v[0];
+    const int nb = min(8, C - pl * 8);  // uniform
+    if (pl == 0) {
+      float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (pl * 8 + j < C) {
-        const float d = v[j] - s0;
-        a += d;
-        b += d * d;
-      }
+      for (int j = 0; j < 8; ++j) s += j < nb ? v[j] : 0.f;
+      s0 = s / (float)nb;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] -= s0;
+    float sb = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sb += j < nb ? v[j] : 0.f;
+    const float mb = sb / (float)nb;
+    float m2b = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = v[j] - mb;
+      m2b += j < nb ? d * d : 0.f;
+    }
+    const int nn = cnt + nb;
+    const float d = mb - mean;
+    mean += d * ((float)nb / (float)nn);
+    m2 += m2b + d * d * ((float)cnt * (float)nb / (float)nn);
+    cnt = nn;
   }
-  const float ma = a / (float)C;
-  const float mean = s0 + ma;
-  const float var = fmaxf(b / (float)C - ma * ma, 0.f);
+  const float var = m2 / (float)C;
+  mean += s0;
   stats[((int64_t)n * HW + pix) * 2] = mean;
   stats[((int64_t)n * HW + pix) * 2 + 1] = 1.f / sqrtf(var + eps);
 }

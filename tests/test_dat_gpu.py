@@ -367,3 +367,26 @@ def test_stream_kernels_on_fp16_planes(device):
     torch.cuda.synchronize()
     got = tensors.planes_to_nchw(out3, heads * 32).cpu().reshape(n, heads, 32, N)
     assert (got[:, :, :hd] - ref).abs().max().item() <= tol(ref)
+
+
+@pytest.mark.parametrize('c,offset,spread', [(180, 0.0, 1.0), (180, 300.0, 0.05), (52, -40.0, 2.0), (8, 5.0, 0.01)])
+def test_plane_stats_single_pass_is_robust(device, c, offset, spread):
+    """Round 4: rsa_plane_stats makes ONE pass over the planes (per-plane (mean, M2), combined pairwise).  Per-pixel mean and 1/sqrt(var + eps)
+    against f64 on data far from zero (a shifted sum of squares would cancel there) and on a channel count that ends inside a plane."""
+    n, h, w = 2, 11, 23
+    x = _q16(_rand((n, c, h, w), 7, spread) + offset)  # hi + lo bf16 planes hold these values exactly
+    cpad = (c + 7) // 8 * 8
+    xpad = torch.zeros((n, cpad, h, w))
+    xpad[:, :c] = x
+    xpad[:, c:] = 777.0  # padding channels must not enter the statistics
+    xp = tensors.nchw_to_planes(xpad.to(device))
+    stats = torch.empty((n, h * w, 2), dtype=torch.float32, device=device)
+    lib = L.load()
+    L.check(lib.rsa_plane_stats(xp.hi_ptr(), xp.lo_ptr(), xp.plane_stride, xp.batch_stride, n, h, w, c, 1e-5, stats.data_ptr(), _stream(device)), 'rsa_plane_stats')
+    torch.cuda.synchronize()
+    xd = x.double().permute(0, 2, 3, 1).reshape(n, h * w, c)
+    mean = xd.mean(-1)
+    rstd = 1.0 / torch.sqrt(xd.var(-1, unbiased=False) + 1e-5)
+    got = stats.cpu().double()
+    assert (got[..., 0] - mean).abs().max().item() <= 2e-6 * max(1.0, abs(offset))
+    assert ((got[..., 1] - rstd).abs() / rstd).max().item() <= 2e-5
