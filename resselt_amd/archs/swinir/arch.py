@@ -16,6 +16,8 @@ from __future__ import annotations
 import ctypes as C
 import math
 
+import os
+
 import torch
 
 from ...engine import lib as L
@@ -214,6 +216,8 @@ class SwinIR(EngineModule):
     # layer-by-layer path (LayerNorm, Linear layers as k1 convolutions, rsa_window_attention).  The fused kernels take C <= 256,
     # <= 8 heads of <= 32 channels, window <= 8, hidden <= 512; other widths run layer by layer whatever this says.
     fused_blocks = 'whole'
+    tail_slices = os.environ.get('RSA_SWIN_TAIL_SLICES', '0') != '0'  # 3conv tails: the C/4 -> C convolution as <= 64-channel slices on the ring. Correct
+    # (the GPU suite passes with it) but 2 % SLOWER on C4 than the one chunk-barrier launch (profiles/r04_y_swin_tail_slices_ab.txt): off
     # 'mixed' (what 'auto' selects when every block runs as one fused launch): the transformer blocks and the convolution that closes each
     # residual group -- 95 % of the multiply-accumulates, all of them feeding the f32 residual stream through a LayerNorm -- run ONE fp16
     # product per multiply (weights, LayerNorm outputs, q / k / v, softmax probabilities, hidden activations rounded to 11 bits, f32
@@ -292,6 +296,15 @@ class SwinIR(EngineModule):
         def resi_conv(name):
             for sub in ([''] if self.resi == '1conv' else ['.0', '.2', '.4']):
                 conv(name + sub)
+            if self.resi == '3conv' and self.tail_slices:
+                # Round 4: the last convolution of a 3conv tail (C/4 -> C, e.g. 60 -> 240) as output-channel SLICES of at most 64 channels: each
+                # slice has whole 32-channel input chunks and 33..64 output channels, i.e. it takes the ring schedule (the whole layer ran the
+                # chunk-barrier kernel: 0.82 ms per 1024^2 map; the four ring launches with their generic f32-residual epilogues take longer: profiles/r04_y_*).  One image per launch list only: a
+                # slice of an f32 map is a channel view, contiguous for one image.
+                w, b = sd[f'{name}.4.weight'], sd.get(f'{name}.4.bias')
+                prod, fmt = self.layer_policy(f'{name}.4') if mixed else (int(products), products.fmt)
+                for k, c0 in enumerate(range(0, w.shape[0], 64)):
+                    W[f'{name}.4.s{k}'] = ops.ConvWeights.from_oihw(w[c0 : c0 + 64], None if b is None else b[c0 : c0 + 64], prod, device=device, fmt=fmt)
 
         conv('conv_first')
         if self.patch_norm:
@@ -480,7 +493,14 @@ class SwinIR(EngineModule):
                 lre = dict(act=L.ACT_LRELU, act_param=0.2)
                 plan.conv(ops.conv_params(W[f'{name}.0'], src_planes, H, Wd, cin_planes=cp, out=q4_a, **lre))
                 plan.conv(ops.conv_params(W[f'{name}.2'], q4_a, H, Wd, out=q4_b, **lre))
-                plan.conv(ops.conv_params(W[f'{name}.4'], q4_b, H, Wd, res1=res, alpha=1.0, out_f32=out_f32, out=out_planes))
+                if n == 1 and f'{name}.4.s0' in W and C_ % 8 == 0:
+                    for k, c0 in enumerate(range(0, C_, 64)):
+                        cw = min(64, C_ - c0)
+                        plan.conv(ops.conv_params(W[f'{name}.4.s{k}'], q4_b, H, Wd, res1=res[:, c0 // 4 : (c0 + cw) // 4], alpha=1.0,
+                                                  out_f32=None if out_f32 is None else out_f32[:, c0 // 4 : (c0 + cw) // 4],
+                                                  out=out_planes, out_plane_off=c0 // 8))  # fmt: skip
+                else:
+                    plan.conv(ops.conv_params(W[f'{name}.4'], q4_b, H, Wd, res1=res, alpha=1.0, out_f32=out_f32, out=out_planes))
 
         plan.conv(ops.conv_params(W['conv_first'], x_pl, H, Wd, out_f32=first))
         free = list(pool)
